@@ -1,0 +1,79 @@
+"""Pin the CPU oracle against the reference's own regression values.
+
+Each case reproduces a deck under /root/reference/source/calibr8/test/primal/ on the
+shipped cube mesh (tests/golden/cube_tet4.json, generated from test/mesh/cube/cube.msh):
+same material, boundary conditions, load steps and tolerances; the expected value and
+its tolerance are the deck's `regression:` block.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from fe_driver import Dbc, Primal, Tbc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def cube():
+    d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
+    d["coords"] = np.array(d["coords"], dtype=np.float64)
+    d["conn"] = np.array(d["conn"], dtype=np.int32)
+    return d
+
+
+def sym_dbcs(cube):
+    ns = cube["node_sets"]
+    return [Dbc(0, 0, ns["xmin"], lambda x, y, z, t: 0.0),
+            Dbc(0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            Dbc(0, 2, ns["zmin"], lambda x, y, z, t: 0.0)]
+
+
+def rel(a, b):
+    return abs((a - b) / b)
+
+
+def test_cube_elastic(cube):
+    # primal/cube_elastic.yaml.in:21-27 (material), :30-34 (bcs), :40-41 (pin); also analytic:
+    # free thermal expansion eps = cte*dT = 0.01 => integral of (ux+uy+uz)/3 over the unit cube = 0.005
+    be = ol.Oracle(ol.TET4, cube["coords"], cube["conn"], "elastic", [1000.0, 0.25, 1.0e-3, 10.0])
+    pr = Primal(be, cube["coords"], sym_dbcs(cube), max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(1)
+    assert rel(pr.qoi(), 5.00000000000000184e-3) < 1.0e-6
+    assert rel(pr.qoi(), 5.0e-3) < 1.0e-10
+
+
+def hyper_j2(cube, Y):
+    # E nu Y S D A n K  (hyper_J2.cpp:83-90)
+    return ol.Oracle(ol.TET4, cube["coords"], cube["conn"], "hyper_J2",
+                     [1000.0, 0.25, Y, 0.0, 0.0, 0.0, 0.0, 100.0], max_iters=30, abs_tol=1e-12, rel_tol=1e-12)
+
+
+def test_cube_hyper_J2(cube):
+    # primal/cube_hyper_J2.yaml.in: 10 steps, ymax pulled by 0.01*t, pin :48-49
+    be = hyper_j2(cube, 10.0)
+    dbcs = sym_dbcs(cube) + [Dbc(0, 1, cube["node_sets"]["ymax"], lambda x, y, z, t: 0.01 * t)]
+    pr = Primal(be, cube["coords"], dbcs, max_iters=15).solve(10)
+    assert rel(pr.qoi(), 1.57817536611772440e-02) < 1.0e-4
+    # plasticity was active: equivalent plastic strain alpha > 0 at the last step
+    assert pr.xi[-1][:, :, 7].max() > 1e-3
+
+
+def test_cube_hyperelasticity(cube):
+    # primal/cube_hyperelasticity.yaml.in: 4 steps, Y = 1e5 (never yields), max 3 Newton iters, pin :48-49
+    be = hyper_j2(cube, 100000.0)
+    dbcs = sym_dbcs(cube) + [Dbc(0, 1, cube["node_sets"]["ymax"], lambda x, y, z, t: 0.001 * t)]
+    pr = Primal(be, cube["coords"], dbcs, max_iters=3).solve(4)
+    assert rel(pr.qoi(), 8.34720846455980019e-04) < 1.0e-4
+
+
+def test_cube_hyperelasticity_traction(cube):
+    # primal/cube_hyperelasticity_traction.yaml.in: clamp ymin, traction 0.1*t on ymax, pin :51-52
+    be = hyper_j2(cube, 100000.0)
+    ns = cube["node_sets"]
+    dbcs = [Dbc(0, d, ns["ymin"], lambda x, y, z, t: 0.0) for d in range(3)]
+    tbcs = [Tbc(0, cube["side_sets"]["ymax"], lambda x, y, z, t: (0.0, 0.1 * t, 0.0))]
+    pr = Primal(be, cube["coords"], dbcs, tbcs, max_iters=10).solve(4)
+    assert rel(pr.qoi(), 1.61757374785081228e-04) < 1.0e-4
