@@ -1,0 +1,476 @@
+// c8_assemble.hpp -- per-element assembly algorithms, written once in SPMD form.
+//
+// An element is processed by a LANE GROUP of E::NDOF lanes (32 for hex8, 16 for
+// tet4): lane k of the group owns derivative slot k of the element's forward-AD
+// dual numbers (slot order = element DOF order, global_residual.cpp:21-23), so
+// after the point loop lane k holds column k of the element Jacobian dR/dx and
+// entry k of the element residual.  A 64-lane wavefront carries 64/NDOF groups.
+//
+// The algorithm is the reference's per-point sequence (evaluations.cpp:79-134):
+//   local Newton solve with xi seeded      -> converged xi, dC/dxi
+//   re-evaluate with x seeded              -> dC/dx
+//   dxi/dx = -(dC/dxi)^-1 dC/dx            -> chain-rule seeds for xi
+//   weak-form integrand with both seeded   -> R_e, dR_e/dx
+// with three implementation differences that do not change the mathematics:
+// the weak form is evaluated as point fluxes and contracted with grad N
+// (c8_models.hpp), element contributions are summed over points before the
+// single scatter, and the 7x7/8x8 solves are one cooperative Gauss-Jordan with
+// row pivoting per group instead of a full-pivot LU per right-hand side.
+//
+// The code is generic over an executor `EX` so that exactly this source runs
+//   * inside the HIP kernels (c8_kernels.hip): each() runs the body once for
+//     the calling lane, shared state lives in LDS, sync() is a wave-level fence;
+//   * in tests/emul (CPU): each() loops the lanes of one group serially.
+// The CPU instantiation exists only to unit-test kernel logic without a GPU;
+// the product never executes it.
+#pragma once
+
+#include <stdint.h>
+
+#include "c8_element.hpp"
+#include "c8_models.hpp"
+
+namespace c8 {
+
+// ---- arguments shared by all assembly kernels (device pointers on the GPU) ----
+struct MeshTables {
+  int32_t const* conn;       // [nelems][NN]
+  double const* coords;      // [nnodes][3]
+  int32_t const* nodeptr;    // [nnodes+1] node-graph row offsets (sorted neighbour lists)
+  uint8_t const* pos;        // [nelems][NN(col node)][NN(row node)] position of col node in row node's list
+  int32_t const* elem_set;   // [nelems] or null (single set)
+  int32_t const* order;      // element processing order (colour-sorted) or null
+  double const* params;      // [nsets][NPARAMS]
+};
+struct ModelSettings {
+  double stab_mult;
+  double abs_tol, rel_tol;
+  int max_iters;
+};
+struct FieldArgs {
+  double const* u;        // [nnodes][3]
+  double const* p;        // [nnodes]
+  double const* u_prev;
+  double const* p_prev;
+  double const* xi_prev;  // [nelems][NP0][NLOC]
+  double* xi;             // [nelems][NP0][NLOC]
+};
+struct SystemArgs {
+  double* A[2][2];  // CSR values of the four blocks
+  double* b[2];     // residual vectors
+  int* status;      // device int: set nonzero when a local Newton solve fails
+  int atomic;       // 1: atomic adds; 0: plain read-modify-write (colour-batched launch)
+};
+
+// ---- per-group shared scratch (LDS) -------------------------------------------
+template <class E, int NL> struct GroupShared {
+  static constexpr int NPT = (E::NP0 > E::NP1) ? E::NP0 : E::NP1;
+  double X[E::NN][3];
+  double u[E::NN][3], p[E::NN];
+  double u_prev[E::NN][3];
+  double N[NPT][E::NN];
+  double dN[NPT][E::NN][3];
+  double wdv[NPT];
+  double M[NL][NL + 1];
+  double h;
+  int32_t node[E::NN];
+  int32_t nptr[E::NN], deg[E::NN];
+};
+
+// ---- shape tables: N, dN/dx, w*detJ for every point of an ip set ---------------
+template <class E, class SH> C8_HD void shape_entry(SH& sh, int ip_set, int pt, int n0, int n1) {
+  double xi[3], w;
+  E::point(ip_set, pt, xi, w);
+  // J(a,b) = d x_b / d xi_a
+  double J[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  for (int n = 0; n < E::NN; ++n) {
+    double g[3];
+    E::dNdxi(n, xi, g);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) J[a][b] += g[a] * sh.X[n][b];
+  }
+  Tens3<double> Jt;
+  Jt.xx = J[0][0]; Jt.xy = J[0][1]; Jt.xz = J[0][2];
+  Jt.yx = J[1][0]; Jt.yy = J[1][1]; Jt.yz = J[1][2];
+  Jt.zx = J[2][0]; Jt.zy = J[2][1]; Jt.zz = J[2][2];
+  double const dJ = det(Jt);
+  Tens3<double> const Ji = inverse(Jt);
+  if (n0 == 0) sh.wdv[pt] = w * dJ;
+  for (int n = n0; n < n1; ++n) {
+    double g[3];
+    E::dNdxi(n, xi, g);
+    sh.N[pt][n] = E::N(n, xi);
+    sh.dN[pt][n][0] = Ji.xx * g[0] + Ji.xy * g[1] + Ji.xz * g[2];
+    sh.dN[pt][n][1] = Ji.yx * g[0] + Ji.yy * g[1] + Ji.yz * g[2];
+    sh.dN[pt][n][2] = Ji.zx * g[0] + Ji.zy * g[1] + Ji.zz * g[2];
+  }
+}
+
+template <class E, class EX, class SH> C8_HD void shape_tables(EX& ex, SH& sh, int ip_set) {
+  int const npts = ip_set == 0 ? E::NP0 : E::NP1;
+  int const lanes_per_pt = E::NDOF / npts;                                // hex8: 4, tet4: 16 / 4
+  int const nodes_per_lane = (E::NN + lanes_per_pt - 1) / lanes_per_pt;   // hex8: 2, tet4: 1
+  ex.each([&](int k) {
+    int const pt = k / lanes_per_pt, sub = k % lanes_per_pt;
+    int const n0 = sub * nodes_per_lane;
+    int const n1 = (n0 + nodes_per_lane < E::NN) ? n0 + nodes_per_lane : E::NN;
+    if (pt < npts && n0 < E::NN) shape_entry<E>(sh, ip_set, pt, n0, n1);
+  });
+  ex.sync();
+}
+
+// mean-square edge length, mechanics.cpp:103-113
+template <class E, class SH> C8_HD double elem_size(SH const& sh) {
+  double h = 0.;
+  for (int e = 0; e < E::NEDGES; ++e) {
+    int a, b;
+    E::edge(e, a, b);
+    double const dx = sh.X[b][0] - sh.X[a][0], dy = sh.X[b][1] - sh.X[a][1], dz = sh.X[b][2] - sh.X[a][2];
+    h += dx * dx + dy * dy + dz * dz;
+  }
+  return sqrt(h / E::NEDGES);
+}
+
+// ---- interpolation (global_residual.cpp:289-332) --------------------------------
+// Values are the same in every lane; the tangent of lane k (x seeded along element
+// DOF k) is a single shape-function entry, no sum needed.
+template <class E, class T, bool PREV, class SH>
+C8_HD void interpolate_values(SH const& sh, int pt, PointState<T>& g) {
+  double u[3] = {0., 0., 0.}, gu[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  double p = 0., gp[3] = {0., 0., 0.};
+  double gup[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  for (int n = 0; n < E::NN; ++n) {
+    double const Nn = sh.N[pt][n];
+    double const d0 = sh.dN[pt][n][0], d1 = sh.dN[pt][n][1], d2 = sh.dN[pt][n][2];
+    for (int i = 0; i < 3; ++i) {
+      double const un = sh.u[n][i];
+      u[i] += un * Nn;
+      gu[i][0] += un * d0; gu[i][1] += un * d1; gu[i][2] += un * d2;
+      if (PREV) {
+        double const upn = sh.u_prev[n][i];
+        gup[i][0] += upn * d0; gup[i][1] += upn * d1; gup[i][2] += upn * d2;
+      }
+    }
+    double const pn = sh.p[n];
+    p += pn * Nn;
+    gp[0] += pn * d0; gp[1] += pn * d1; gp[2] += pn * d2;
+  }
+  for (int i = 0; i < 3; ++i) { g.u[i] = T(u[i]); g.grad_p[i] = T(gp[i]); }
+  g.p = T(p);
+  g.grad_u.xx = T(gu[0][0]); g.grad_u.xy = T(gu[0][1]); g.grad_u.xz = T(gu[0][2]);
+  g.grad_u.yx = T(gu[1][0]); g.grad_u.yy = T(gu[1][1]); g.grad_u.yz = T(gu[1][2]);
+  g.grad_u.zx = T(gu[2][0]); g.grad_u.zy = T(gu[2][1]); g.grad_u.zz = T(gu[2][2]);
+  g.grad_u_prev.xx = T(gup[0][0]); g.grad_u_prev.xy = T(gup[0][1]); g.grad_u_prev.xz = T(gup[0][2]);
+  g.grad_u_prev.yx = T(gup[1][0]); g.grad_u_prev.yy = T(gup[1][1]); g.grad_u_prev.yz = T(gup[1][2]);
+  g.grad_u_prev.zx = T(gup[2][0]); g.grad_u_prev.zy = T(gup[2][1]); g.grad_u_prev.zz = T(gup[2][2]);
+}
+
+// seed_wrt_x for lane k (global_residual.cpp:206-216): d(interpolant)/d(x_k)
+template <class E, class SH> C8_HD void seed_x(SH const& sh, int pt, int k, PointState<Dual>& g, bool prev = false) {
+  int i, n, eq;
+  slot_to_dof<E>(k, i, n, eq);
+  double const Nn = sh.N[pt][n];
+  double const d0 = sh.dN[pt][n][0], d1 = sh.dN[pt][n][1], d2 = sh.dN[pt][n][2];
+  bool const isu = (i == 0), isp = (i == 1);
+  Tens3<Dual>& G = prev ? g.grad_u_prev : g.grad_u;
+  if (!prev) {
+    g.u[0].d = (isu && eq == 0) ? Nn : 0.;
+    g.u[1].d = (isu && eq == 1) ? Nn : 0.;
+    g.u[2].d = (isu && eq == 2) ? Nn : 0.;
+    g.p.d = isp ? Nn : 0.;
+    g.grad_p[0].d = isp ? d0 : 0.;
+    g.grad_p[1].d = isp ? d1 : 0.;
+    g.grad_p[2].d = isp ? d2 : 0.;
+  }
+  G.xx.d = (isu && eq == 0) ? d0 : 0.; G.xy.d = (isu && eq == 0) ? d1 : 0.; G.xz.d = (isu && eq == 0) ? d2 : 0.;
+  G.yx.d = (isu && eq == 1) ? d0 : 0.; G.yy.d = (isu && eq == 1) ? d1 : 0.; G.yz.d = (isu && eq == 1) ? d2 : 0.;
+  G.zx.d = (isu && eq == 2) ? d0 : 0.; G.zy.d = (isu && eq == 2) ? d1 : 0.; G.zz.d = (isu && eq == 2) ? d2 : 0.;
+}
+C8_HD void unseed(PointState<Dual>& g) {
+  for (int i = 0; i < 3; ++i) { g.u[i].d = 0.; g.grad_p[i].d = 0.; }
+  g.p.d = 0.;
+  Tens3<Dual>* t[2] = {&g.grad_u, &g.grad_u_prev};
+  for (int q = 0; q < 2; ++q) {
+    t[q]->xx.d = 0.; t[q]->xy.d = 0.; t[q]->xz.d = 0.;
+    t[q]->yx.d = 0.; t[q]->yy.d = 0.; t[q]->yz.d = 0.;
+    t[q]->zx.d = 0.; t[q]->zy.d = 0.; t[q]->zz.d = 0.;
+  }
+}
+
+// ---- cooperative Gauss-Jordan with row pivoting ----------------------------------
+// M (NL x NL, in group-shared memory) is destroyed; every lane passes its own
+// right-hand side b[NL] (registers) and gets its solution back in b.  Lane c < NL
+// owns column c of M.  Replaces Eigen fullPivLu().solve() (evaluations.cpp:112,
+// small_J2.cpp:157); returns false on a zero pivot.
+template <int NL, class EX, class SH, class GetB>
+C8_HD bool gj_solve(EX& ex, SH& sh, GetB getb) {
+  bool ok = true;
+  for (int s = 0; s < NL; ++s) {
+    ex.each([&](int k) {
+      double* b = getb(k);
+      double col[NL];
+      for (int r = 0; r < NL; ++r) col[r] = sh.M[r][s];
+      int rstar = s;
+      double big = fabs(col[s]);
+      for (int r = s + 1; r < NL; ++r) {
+        double const a = fabs(col[r]);
+        if (a > big) { big = a; rstar = r; }
+      }
+      if (!(big > 0.)) ok = false;
+      // swap rows s <-> rstar in this lane's copies (compile-time slots, run-time rstar)
+      double const cs = col[s], bs = b[s];
+      double cpiv = cs, bpiv = bs;
+      for (int r = s + 1; r < NL; ++r) {
+        if (r == rstar) { cpiv = col[r]; bpiv = b[r]; col[r] = cs; b[r] = bs; }
+      }
+      double const inv = 1. / cpiv;
+      double const bsn = bpiv * inv;
+      b[s] = bsn;
+      for (int r = 0; r < NL; ++r) if (r != s) b[r] -= col[r] * bsn;
+      if (k > s && k < NL) {  // column owner updates M[:, k]
+        double const ms = sh.M[s][k], mr = sh.M[rstar][k];
+        sh.M[rstar][k] = ms;
+        double const msn = mr * inv;
+        sh.M[s][k] = msn;
+        for (int r = 0; r < NL; ++r) if (r != s) sh.M[r][k] -= col[r] * msn;
+      }
+    });
+    ex.sync();
+  }
+  return ok;
+}
+
+// ---- lane state for the forward (primal) assembly -----------------------------------
+template <class E, template <class> class ModelT> struct ForwardLane {
+  using Model = ModelT<Dual>;
+  double Jcol[E::NDOF];  // column k of dR_e/dx
+  double Rk;             // entry k of R_e
+  Model m;
+  PointState<Dual> g;
+  double b[Model::NLOC];
+  int iter;
+  double R_norm_0;
+  bool converged, failed;
+};
+
+template <class Model> C8_HD void load_params(Model& m, MeshTables const& mt, int e) {
+  int const es = mt.elem_set ? mt.elem_set[e] : 0;
+  for (int q = 0; q < Model::NPARAMS; ++q) m.params[q] = Dual(mt.params[es * Model::NPARAMS + q]);
+}
+
+template <class E, class EX, class SH>
+C8_HD void load_element(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& fa, int e, bool prev) {
+  ex.each([&](int k) {
+    int i, n, eq;
+    slot_to_dof<E>(k, i, n, eq);
+    int const node = mt.conn[e * E::NN + n];
+    if (i == 0) {
+      sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
+      sh.u[n][eq] = fa.u[(size_t)node * 3 + eq];
+      if (prev) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * 3 + eq];
+    } else {
+      sh.p[n] = fa.p[node];
+      sh.node[n] = node;
+      if (mt.nodeptr) {
+        int const a = mt.nodeptr[node];
+        sh.nptr[n] = a;
+        sh.deg[n] = mt.nodeptr[node + 1] - a;
+      }
+    }
+  });
+  ex.sync();
+}
+
+// add the weak-form contribution of one point to lane k's Jacobian column / residual entry
+template <class E, class SH>
+C8_HD void accumulate_coupled(SH const& sh, int pt, int k, MechFlux<Dual> const& f, double* Jcol, double& Rk) {
+  double const wdv = sh.wdv[pt];
+  int ik, nk, eqk;
+  slot_to_dof<E>(k, ik, nk, eqk);
+  for (int n = 0; n < E::NN; ++n) {
+    double const d0 = sh.dN[pt][n][0] * wdv, d1 = sh.dN[pt][n][1] * wdv, d2 = sh.dN[pt][n][2] * wdv;
+    Jcol[3 * n + 0] += f.Gu.xx.d * d0 + f.Gu.xy.d * d1 + f.Gu.xz.d * d2;
+    Jcol[3 * n + 1] += f.Gu.yx.d * d0 + f.Gu.yy.d * d1 + f.Gu.yz.d * d2;
+    Jcol[3 * n + 2] += f.Gu.zx.d * d0 + f.Gu.zy.d * d1 + f.Gu.zz.d * d2;
+    Jcol[3 * E::NN + n] += f.Vp.d * (sh.N[pt][n] * wdv) + f.Gp[0].d * d0 + f.Gp[1].d * d1 + f.Gp[2].d * d2;
+  }
+  double const d0 = sh.dN[pt][nk][0] * wdv, d1 = sh.dN[pt][nk][1] * wdv, d2 = sh.dN[pt][nk][2] * wdv;
+  double const r0 = f.Gu.xx.v * d0 + f.Gu.xy.v * d1 + f.Gu.xz.v * d2;
+  double const r1 = f.Gu.yx.v * d0 + f.Gu.yy.v * d1 + f.Gu.yz.v * d2;
+  double const r2 = f.Gu.zx.v * d0 + f.Gu.zy.v * d1 + f.Gu.zz.v * d2;
+  double const rp = f.Vp.v * (sh.N[pt][nk] * wdv) + f.Gp[0].v * d0 + f.Gp[1].v * d1 + f.Gp[2].v * d2;
+  Rk += (ik == 1) ? rp : (eqk == 0 ? r0 : (eqk == 1 ? r1 : r2));
+}
+
+// ---- scatter (global_residual.cpp:463-479 scatter_rhs, :556-586 scatter_lhs) ------
+// The CSR position of (row dof, col dof) follows from the node graph alone, because
+// every block stores all equations of a neighbour node contiguously and sorted:
+//   rowptr_ij[n*neq_i + eq_i] = nodeptr[n]*neq_i*neq_j + eq_i*deg[n]*neq_j
+//   offset = rowptr + pos(row node, col node)*neq_j + eq_j
+// so the reference's 4 KB/element scatter_offsets table (disc.cpp:414-459) is replaced
+// by 64 bytes of positions per element.  If `transpose`, lane k holds ROW k.
+template <class E, class EX, class SH, class GetJ>
+C8_HD void scatter_lhs(EX& ex, SH const& sh, MeshTables const& mt, SystemArgs const& sa, int e, bool transpose, GetJ getj) {
+  ex.each([&](int k) {
+    double const* Jc = getj(k);
+    int ik, nk, eqk;
+    slot_to_dof<E>(k, ik, nk, eqk);
+    int const neqk = ik == 0 ? 3 : 1;
+    uint8_t const* posk = mt.pos + ((size_t)e * E::NN + nk) * E::NN;  // pos[e][col node nk][row node]
+    for (int a = 0; a < E::NDOF; ++a) {
+      int ia, na, eqa;
+      slot_to_dof<E>(a, ia, na, eqa);
+      int const neqa = ia == 0 ? 3 : 1;
+      size_t off;
+      double* vals;
+      if (!transpose) {  // entry (row a, col k)
+        off = (size_t)sh.nptr[na] * (neqa * neqk) + (size_t)eqa * sh.deg[na] * neqk + (size_t)posk[na] * neqk + eqk;
+        vals = sa.A[ia][ik];
+      } else {           // entry (row k, col a): position of node na in row node nk's list
+        uint8_t const pka = mt.pos[((size_t)e * E::NN + na) * E::NN + nk];
+        off = (size_t)sh.nptr[nk] * (neqk * neqa) + (size_t)eqk * sh.deg[nk] * neqa + (size_t)pka * neqa + eqa;
+        vals = sa.A[ik][ia];
+      }
+      ex.add(vals + off, Jc[a], sa.atomic);
+    }
+  });
+}
+
+template <class E, class EX, class SH, class GetR>
+C8_HD void scatter_rhs(EX& ex, SH const& sh, SystemArgs const& sa, GetR getr) {
+  ex.each([&](int k) {
+    int ik, nk, eqk;
+    slot_to_dof<E>(k, ik, nk, eqk);
+    int const neqk = ik == 0 ? 3 : 1;
+    ex.add(sa.b[ik] + (size_t)sh.node[nk] * neqk + eqk, getr(k), sa.atomic);
+  });
+}
+
+// =====================================================================================
+// K1: eval_forward_jacobian (evaluations.cpp:12-154) for one element.
+// =====================================================================================
+template <class E, template <class> class ModelT, class EX>
+C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
+                                    ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
+  using Model = ModelT<Dual>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  using Lane = ForwardLane<E, ModelT>;
+
+  load_element<E>(ex, sh, mt, fa, e, PREV);
+  ex.each([&](int k) {
+    Lane& r = ex.lane(k);
+    for (int a = 0; a < E::NDOF; ++a) r.Jcol[a] = 0.;
+    r.Rk = 0.;
+    r.failed = false;
+    load_params(r.m, mt, e);
+    if (k == 0) sh.h = elem_size<E>(sh);
+  });
+  ex.sync();
+
+  for (int ip_set = 0; ip_set < 2; ++ip_set) {
+    if (ip_set == 0 || !E::SAME_POINTS) shape_tables<E>(ex, sh, ip_set);
+    int const npts = ip_set == 0 ? E::NP0 : E::NP1;
+    for (int pt = 0; pt < npts; ++pt) {
+      if (ip_set == 0) {
+        size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+        // --- local->gather, seed_wrt_xi, solve_nonlinear (small_J2.cpp:122-173) ---
+        ex.each([&](int k) {
+          Lane& r = ex.lane(k);
+          interpolate_values<E, Dual, PREV>(sh, pt, r.g);
+          for (int j = 0; j < NL; ++j) {
+            r.m.xi_prev[j] = Dual(fa.xi_prev[q + j]);
+            r.m.xi[j] = Dual(fa.xi[q + j], (j == k) ? 1. : 0.);
+            r.m.R[j] = Dual(0.);
+          }
+          r.m.initial_guess(r.g);
+          r.iter = 1;
+          r.R_norm_0 = 1.;
+          r.converged = !Model::HAS_LOCAL;
+        });
+        if (Model::HAS_LOCAL) {
+          while (ex.any([&](int k) { Lane& r = ex.lane(k); return (r.iter <= ms.max_iters) && !r.converged; })) {
+            ex.each([&](int k) {
+              Lane& r = ex.lane(k);
+              if (!((r.iter <= ms.max_iters) && !r.converged)) return;
+              r.m.evaluate(r.g, ms.abs_tol);
+              double nrm = 0.;
+              for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
+              double const R_norm = sqrt(nrm);
+              if (r.iter == 1) r.R_norm_0 = R_norm;
+              double const R_norm_rel = R_norm / r.R_norm_0;  // NaN on elastic points: the abs test decides
+              if ((R_norm_rel < ms.rel_tol) || (R_norm < ms.abs_tol)) r.converged = true;
+              if (k < NL) for (int j = 0; j < NL; ++j) sh.M[j][k] = r.m.R[j].d;
+              for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].v;
+            });
+            ex.sync();
+            if (!ex.any([&](int k) { Lane& r = ex.lane(k); return (r.iter <= ms.max_iters) && !r.converged; })) break;
+            bool const ok = gj_solve<NL>(ex, sh, [&](int k) { return ex.lane(k).b; });
+            ex.each([&](int k) {
+              Lane& r = ex.lane(k);
+              if (!ok) { r.failed = true; r.iter = ms.max_iters + 1; return; }
+              for (int j = 0; j < NL; ++j) r.m.xi[j].v += r.b[j];
+              r.iter++;
+            });
+          }
+          ex.each([&](int k) {
+            Lane& r = ex.lane(k);
+            if ((r.iter > ms.max_iters) && !r.converged) r.failed = true;
+          });
+        }
+        // --- local->scatter; dC/dxi is in sh.M from the last evaluate; unseed xi; seed x;
+        //     evaluate -> dC/dx; dxi/dx = -(dC/dxi)^-1 dC/dx  (evaluations.cpp:101-115) ---
+        ex.each([&](int k) {
+          Lane& r = ex.lane(k);
+          if (k < NL) {
+            double v = r.m.xi[0].v;
+            for (int j = 1; j < NL; ++j) if (j == k) v = r.m.xi[j].v;
+            fa.xi[q + k] = v;
+          }
+          for (int j = 0; j < NL; ++j) r.m.xi[j].d = 0.;
+          seed_x<E>(sh, pt, k, r.g);
+          if (Model::HAS_LOCAL) {
+            r.m.evaluate(r.g, ms.abs_tol);
+            for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].d;
+          }
+        });
+        if (Model::HAS_LOCAL) {
+          ex.sync();
+          bool const ok = gj_solve<NL>(ex, sh, [&](int k) { return ex.lane(k).b; });
+          ex.each([&](int k) {
+            Lane& r = ex.lane(k);
+            if (!ok) r.failed = true;
+            for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];  // local->seed_wrt_x(dxi_dx)
+          });
+        }
+        // --- global->evaluate + accumulate (evaluations.cpp:126-131) ---
+        ex.each([&](int k) {
+          Lane& r = ex.lane(k);
+          MechFlux<Dual> f;
+          Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+          accumulate_coupled<E>(sh, pt, k, f, r.Jcol, r.Rk);
+        });
+      } else {
+        ex.each([&](int k) {
+          Lane& r = ex.lane(k);
+          interpolate_values<E, Dual, false>(sh, pt, r.g);
+          seed_x<E>(sh, pt, k, r.g);
+          Dual const Vp = Mechanics::flux_pressure(r.m, r.g);
+          double const wdv = sh.wdv[pt];
+          int ik, nk, eqk;
+          slot_to_dof<E>(k, ik, nk, eqk);
+          for (int n = 0; n < E::NN; ++n) r.Jcol[3 * E::NN + n] += Vp.d * (sh.N[pt][n] * wdv);
+          if (ik == 1) r.Rk += Vp.v * (sh.N[pt][nk] * wdv);
+        });
+      }
+    }
+  }
+  ex.sync();
+  scatter_lhs<E>(ex, sh, mt, sa, e, false, [&](int k) { return ex.lane(k).Jcol; });
+  scatter_rhs<E>(ex, sh, sa, [&](int k) { return ex.lane(k).Rk; });
+  ex.each([&](int k) {
+    if (k == 0 && ex.lane(k).failed) ex.flag(sa.status);
+  });
+}
+
+}  // namespace c8

@@ -1,0 +1,190 @@
+// c8_math.hpp -- scalar and small-tensor types shared by every kernel.
+//
+// Dual: the flat fixed-size forward-AD type that replaces Sacado::Fad::SLFad
+// (reference defines.hpp:23-26).  It carries ONE tangent direction; a lane
+// group of a wavefront carries one direction per lane (lane = derivative
+// slot), so an N-derivative dual number is spread over N lanes and every
+// operation below is one or two FP64 VALU instructions per lane.
+//
+// Tens3: 3x3 tensor with compile-time indices only (no run-time indexed
+// register arrays), the MiniTensor subset of SURVEY.md section 8a row a15.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define C8_HD __host__ __device__ __forceinline__
+#else
+#define C8_HD inline
+#endif
+
+namespace c8 {
+
+struct Dual {
+  double v, d;
+  C8_HD Dual() {}
+  C8_HD Dual(double x) : v(x), d(0.) {}
+  C8_HD Dual(double x, double dx) : v(x), d(dx) {}
+};
+
+C8_HD double val(double x) { return x; }
+C8_HD double val(Dual const& x) { return x.v; }
+C8_HD double der(double) { return 0.; }
+C8_HD double der(Dual const& x) { return x.d; }
+
+C8_HD Dual operator-(Dual const& a) { return Dual(-a.v, -a.d); }
+C8_HD Dual operator+(Dual const& a, Dual const& b) { return Dual(a.v + b.v, a.d + b.d); }
+C8_HD Dual operator-(Dual const& a, Dual const& b) { return Dual(a.v - b.v, a.d - b.d); }
+C8_HD Dual operator*(Dual const& a, Dual const& b) { return Dual(a.v * b.v, a.v * b.d + a.d * b.v); }
+C8_HD Dual operator/(Dual const& a, Dual const& b) {
+  double const r = 1. / b.v;
+  double const q = a.v * r;
+  return Dual(q, (a.d - q * b.d) * r);
+}
+C8_HD Dual operator+(Dual const& a, double b) { return Dual(a.v + b, a.d); }
+C8_HD Dual operator+(double a, Dual const& b) { return Dual(a + b.v, b.d); }
+C8_HD Dual operator-(Dual const& a, double b) { return Dual(a.v - b, a.d); }
+C8_HD Dual operator-(double a, Dual const& b) { return Dual(a - b.v, -b.d); }
+C8_HD Dual operator*(Dual const& a, double b) { return Dual(a.v * b, a.d * b); }
+C8_HD Dual operator*(double a, Dual const& b) { return Dual(a * b.v, a * b.d); }
+C8_HD Dual operator/(Dual const& a, double b) {
+  double const r = 1. / b;
+  return Dual(a.v * r, a.d * r);
+}
+C8_HD Dual operator/(double a, Dual const& b) {
+  double const r = 1. / b.v;
+  double const q = a * r;
+  return Dual(q, -q * b.d * r);
+}
+C8_HD Dual& operator+=(Dual& a, Dual const& b) { a.v += b.v; a.d += b.d; return a; }
+C8_HD Dual& operator-=(Dual& a, Dual const& b) { a.v -= b.v; a.d -= b.d; return a; }
+C8_HD Dual& operator+=(Dual& a, double b) { a.v += b; return a; }
+C8_HD Dual& operator-=(Dual& a, double b) { a.v -= b; return a; }
+
+C8_HD Dual c8_sqrt(Dual const& a) {
+  double const s = sqrt(a.v);
+  return Dual(s, a.d / (2. * s));
+}
+C8_HD double c8_sqrt(double a) { return sqrt(a); }
+C8_HD Dual c8_cbrt(Dual const& a) {
+  double const c = cbrt(a.v);
+  return Dual(c, a.d / (3. * c * c));
+}
+C8_HD double c8_cbrt(double a) { return cbrt(a); }
+C8_HD Dual c8_exp(Dual const& a) {
+  double const e = exp(a.v);
+  return Dual(e, e * a.d);
+}
+C8_HD double c8_exp(double a) { return exp(a); }
+// pow(a, b) with both arguments differentiable (Sacado's rule: zero derivative at a == 0)
+C8_HD Dual c8_pow(Dual const& a, Dual const& b) {
+  double const r = pow(a.v, b.v);
+  double d = 0.;
+  if (a.v != 0.) d = (b.d * log(a.v) + b.v * a.d / a.v) * r;
+  return Dual(r, d);
+}
+C8_HD double c8_pow(double a, double b) { return pow(a, b); }
+
+// ---------------------------------------------------------------------------
+template <class T> struct Tens3 {
+  T xx, xy, xz, yx, yy, yz, zx, zy, zz;
+};
+
+template <class T> C8_HD Tens3<T> eye3() {
+  Tens3<T> r;
+  r.xx = T(1.); r.xy = T(0.); r.xz = T(0.);
+  r.yx = T(0.); r.yy = T(1.); r.yz = T(0.);
+  r.zx = T(0.); r.zy = T(0.); r.zz = T(1.);
+  return r;
+}
+template <class T> C8_HD Tens3<T> operator+(Tens3<T> const& A, Tens3<T> const& B) {
+  Tens3<T> r;
+  r.xx = A.xx + B.xx; r.xy = A.xy + B.xy; r.xz = A.xz + B.xz;
+  r.yx = A.yx + B.yx; r.yy = A.yy + B.yy; r.yz = A.yz + B.yz;
+  r.zx = A.zx + B.zx; r.zy = A.zy + B.zy; r.zz = A.zz + B.zz;
+  return r;
+}
+template <class T> C8_HD Tens3<T> operator-(Tens3<T> const& A, Tens3<T> const& B) {
+  Tens3<T> r;
+  r.xx = A.xx - B.xx; r.xy = A.xy - B.xy; r.xz = A.xz - B.xz;
+  r.yx = A.yx - B.yx; r.yy = A.yy - B.yy; r.yz = A.yz - B.yz;
+  r.zx = A.zx - B.zx; r.zy = A.zy - B.zy; r.zz = A.zz - B.zz;
+  return r;
+}
+template <class S, class T> C8_HD Tens3<T> scale(S const& s, Tens3<T> const& A) {
+  Tens3<T> r;
+  r.xx = s * A.xx; r.xy = s * A.xy; r.xz = s * A.xz;
+  r.yx = s * A.yx; r.yy = s * A.yy; r.yz = s * A.yz;
+  r.zx = s * A.zx; r.zy = s * A.zy; r.zz = s * A.zz;
+  return r;
+}
+template <class T> C8_HD Tens3<T> matmul(Tens3<T> const& A, Tens3<T> const& B) {
+  Tens3<T> r;
+  r.xx = A.xx * B.xx + A.xy * B.yx + A.xz * B.zx;
+  r.xy = A.xx * B.xy + A.xy * B.yy + A.xz * B.zy;
+  r.xz = A.xx * B.xz + A.xy * B.yz + A.xz * B.zz;
+  r.yx = A.yx * B.xx + A.yy * B.yx + A.yz * B.zx;
+  r.yy = A.yx * B.xy + A.yy * B.yy + A.yz * B.zy;
+  r.yz = A.yx * B.xz + A.yy * B.yz + A.yz * B.zz;
+  r.zx = A.zx * B.xx + A.zy * B.yx + A.zz * B.zx;
+  r.zy = A.zx * B.xy + A.zy * B.yy + A.zz * B.zy;
+  r.zz = A.zx * B.xz + A.zy * B.yz + A.zz * B.zz;
+  return r;
+}
+template <class T> C8_HD Tens3<T> transpose(Tens3<T> const& A) {
+  Tens3<T> r;
+  r.xx = A.xx; r.xy = A.yx; r.xz = A.zx;
+  r.yx = A.xy; r.yy = A.yy; r.yz = A.zy;
+  r.zx = A.xz; r.zy = A.yz; r.zz = A.zz;
+  return r;
+}
+template <class T> C8_HD T trace(Tens3<T> const& A) { return A.xx + A.yy + A.zz; }
+template <class T> C8_HD T det(Tens3<T> const& A) {
+  return A.xx * (A.yy * A.zz - A.yz * A.zy) - A.xy * (A.yx * A.zz - A.yz * A.zx) +
+         A.xz * (A.yx * A.zy - A.yy * A.zx);
+}
+// cofactor matrix C with A^{-1} = C^T / det(A)  (mechanics.cpp:85-94 writes the same entries)
+template <class T> C8_HD Tens3<T> cofactor(Tens3<T> const& F) {
+  Tens3<T> C;
+  C.xx = F.yy * F.zz - F.yz * F.zy;
+  C.xy = F.yz * F.zx - F.yx * F.zz;
+  C.xz = F.yx * F.zy - F.yy * F.zx;
+  C.yx = F.xz * F.zy - F.xy * F.zz;
+  C.yy = F.xx * F.zz - F.xz * F.zx;
+  C.yz = F.xy * F.zx - F.xx * F.zy;
+  C.zx = F.xy * F.yz - F.xz * F.yy;
+  C.zy = F.xz * F.yx - F.xx * F.yz;
+  C.zz = F.xx * F.yy - F.xy * F.yx;
+  return C;
+}
+template <class T> C8_HD Tens3<T> inverse(Tens3<T> const& A) {
+  Tens3<T> const C = cofactor(A);
+  T const dt = A.xx * C.xx + A.xy * C.xy + A.xz * C.xz;
+  T const r = 1. / dt;
+  return scale(r, transpose(C));
+}
+template <class T> C8_HD Tens3<T> dev(Tens3<T> const& A) {
+  T const th = trace(A) * (1. / 3.);
+  Tens3<T> r = A;
+  r.xx = A.xx - th; r.yy = A.yy - th; r.zz = A.zz - th;
+  return r;
+}
+template <class T> C8_HD T norm(Tens3<T> const& A) {
+  T const s = A.xx * A.xx + A.xy * A.xy + A.xz * A.xz + A.yx * A.yx + A.yy * A.yy + A.yz * A.yz +
+              A.zx * A.zx + A.zy * A.zy + A.zz * A.zz;
+  return c8_sqrt(s);
+}
+// symmetric tensor from the packed local-variable order (00,01,02,11,12,22)
+// (local_residual.cpp:206-216)
+template <class T> C8_HD Tens3<T> sym6(T const* s) {
+  Tens3<T> r;
+  r.xx = s[0]; r.xy = s[1]; r.xz = s[2];
+  r.yx = s[1]; r.yy = s[3]; r.yz = s[4];
+  r.zx = s[2]; r.zy = s[4]; r.zz = s[5];
+  return r;
+}
+template <class T> C8_HD void pack_sym6(Tens3<T> const& t, T* s) {  // local_residual.cpp:572-577
+  s[0] = t.xx; s[1] = t.xy; s[2] = t.xz; s[3] = t.yy; s[4] = t.yz; s[5] = t.zz;
+}
+
+}  // namespace c8

@@ -1,0 +1,255 @@
+// c8_models.hpp -- device-side residual plug-ins.
+//
+// Same plug-in surface as the reference, templated on the scalar T in
+// {double, Dual}, stateless apart from the per-point registers they own:
+//
+//   LocalResidual concept  (local_residual.hpp:62-158)
+//     NLOC, NPARAMS, FINITE_DEF, HAS_LOCAL, name()
+//     initial_guess(g)            first half of solve_nonlinear
+//     evaluate(g, force, path)    fills R[], returns ELASTIC/PLASTIC
+//     cauchy / dev_cauchy / hydro_cauchy / pressure_scale_factor
+//   GlobalResidual concept (global_residual.hpp:125-130)
+//     Mechanics::flux(local, g, ...)  the integrand of the stabilised mixed
+//     weak form as point fluxes: R(i,n,eq) += [V(i,eq) N_n + G(i,eq,:).grad N_n] w dv
+//
+// A new constitutive model is one struct implementing the LocalResidual
+// concept plus one line in C8_FOR_EACH_MODEL (c8_kernels.hip).
+//
+// Semantics that must not be "simplified" (SURVEY.md section 10): the yield function is
+// scaled by val(mu), not mu (small_J2.cpp:208, hyper_J2.cpp:264); the branch
+// test is f > tol || |f| < tol (small_J2.cpp:215); n = s/|s| is 0/0 at zero
+// strain and may only be read on the plastic branch.
+#pragma once
+
+#include "c8_math.hpp"
+
+namespace c8 {
+
+enum { C8_ELASTIC_PATH = 0, C8_PLASTIC_PATH = 1 };
+
+C8_HD void set_val(double& x, double v) { x = v; }
+C8_HD void set_val(Dual& x, double v) { x.v = v; }  // keeps the seeding (local_residual.cpp:293-296)
+
+// interpolated global state at a quadrature point: the GlobalResidual accessors
+// scalar_x(1), grad_scalar_x(1), vector_x(0), grad_vector_x(0), grad_vector_x_prev(0)
+template <class T> struct PointState {
+  T u[3];
+  T p;
+  T grad_p[3];
+  Tens3<T> grad_u;
+  Tens3<T> grad_u_prev;
+};
+
+template <class T> C8_HD T compute_mu(T const& E, T const& nu) { return E / (2. * (1. + nu)); }       // material_params.hpp:12
+template <class T> C8_HD T compute_kappa(T const& E, T const& nu) { return E / (3. * (1. - 2. * nu)); }  // :20
+
+template <class T> C8_HD Tens3<T> small_strain(Tens3<T> const& g) {
+  Tens3<T> const gt = transpose(g);
+  return scale(0.5, g + gt);
+}
+
+// ---- elastic.cpp:76-136 -----------------------------------------------------
+template <class T> struct Elastic {
+  static constexpr int NLOC = 1, NPARAMS = 4;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = false;
+  T params[NPARAMS];  // E nu cte delta_T
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];
+  C8_HD static void init_variables(double* xi0) { xi0[0] = 0.; }
+  C8_HD void initial_guess(PointState<T> const&) { set_val(xi[0], 0.); }
+  C8_HD int evaluate(PointState<T> const&, double, bool = false, int = 0) { return 0; }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {
+    T const mu = compute_mu(params[0], params[1]);
+    Tens3<T> const eps = small_strain(g.grad_u);
+    return scale(2. * mu, dev(eps));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {
+    T const E = params[0], nu = params[1];
+    T const kappa = compute_kappa(E, nu);
+    return kappa * trace(small_strain(g.grad_u)) - params[2] * params[3] * E / (1. - 2. * nu);
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+};
+
+// ---- small_J2.cpp -------------------------------------------------------------
+template <class T> struct SmallJ2 {
+  static constexpr int NLOC = 7, NPARAMS = 6;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  T params[NPARAMS];  // E nu K Y cte delta_T  (small_J2.cpp:70-75)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
+  C8_HD static void init_variables(double* xi0) { for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD void initial_guess(PointState<T> const&) {  // :127-135
+    for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(xi_prev[k]));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :266-277
+    T const mu = compute_mu(params[0], params[1]);
+    Tens3<T> const eps = small_strain(g.grad_u);
+    Tens3<T> const pstrain = sym6(xi);
+    return scale(2. * mu, dev(eps) - pstrain);
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :253-263
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :280-289
+    T const E = params[0], nu = params[1];
+    T const kappa = compute_kappa(E, nu);
+    return kappa * trace(small_strain(g.grad_u)) - params[4] * params[5] * E / (1. - 2. * nu);
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :181-250
+    double const sqrt_23 = 0.81649658092772603273;
+    double const sqrt_32 = 1.22474487139158904910;
+    T const mu = compute_mu(params[0], params[1]);
+    T const K = params[2], Y = params[3];
+    T const alpha = xi[6], alpha_old = xi_prev[6];
+    Tens3<T> const s = dev_cauchy(g);
+    T const s_mag = norm(s);
+    T const sigma_yield = Y + K * alpha;
+    T const f = (s_mag - sqrt_23 * sigma_yield) / val(mu);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = sqrt_32 * (alpha - alpha_old);
+      T const c = dgam / s_mag;  // dgam * n = (dgam/|s|) s
+      Tens3<T> const Rp = sym6(xi) - sym6(xi_prev) - scale(c, s);
+      pack_sym6(Rp, R);
+      R[6] = f;
+    } else {
+      for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
+    }
+    return path;
+  }
+};
+
+// ---- hyper_J2.cpp -------------------------------------------------------------
+template <class T> struct HyperJ2 {
+  static constexpr int NLOC = 8, NPARAMS = 8;
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2.cpp:83-90)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // zeta(6), Ie, alpha
+  C8_HD static void init_variables(double* xi0) {  // :119-134
+    for (int k = 0; k < NLOC; ++k) xi0[k] = 0.;
+    xi0[6] = 1.;
+  }
+  C8_HD Tens3<T> be_bar_trial(PointState<T> const& g) const {  // eval_be_bar(zeta_old, Ie_old) :137-154
+    Tens3<T> const I = eye3<T>();
+    Tens3<T> const F = g.grad_u + I;
+    Tens3<T> const F_prev = g.grad_u_prev + I;
+    Tens3<T> const rF = matmul(F, inverse(F_prev));
+    T const det_rF_13 = c8_cbrt(det(rF));
+    Tens3<T> const rF_bar = scale(1. / det_rF_13, rF);
+    Tens3<T> be_old = sym6(xi_prev);
+    be_old.xx = be_old.xx + xi_prev[6]; be_old.yy = be_old.yy + xi_prev[6]; be_old.zz = be_old.zz + xi_prev[6];
+    return matmul(matmul(rF_bar, be_old), transpose(rF_bar));
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // :167-178
+    Tens3<T> const bt = be_bar_trial(g);
+    Tens3<T> const z = dev(bt);
+    T zv[6];
+    pack_sym6(z, zv);
+    for (int k = 0; k < 6; ++k) set_val(xi[k], val(zv[k]));
+    set_val(xi[6], val(trace(bt)) / 3.);
+    set_val(xi[7], val(xi_prev[7]));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :327-338
+    T const mu = compute_mu(params[0], params[1]);
+    Tens3<T> const F = g.grad_u + eye3<T>();
+    T const J = det(F);
+    return scale(mu / J, sym6(xi));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :316-324
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :341-352
+    T const kappa = compute_kappa(params[0], params[1]);
+    Tens3<T> const F = g.grad_u + eye3<T>();
+    T const J = det(F);
+    return (kappa * 0.5) * (J - 1. / J);
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :226-314
+    double const sqrt_23 = 0.81649658092772603273;
+    double const sqrt_32 = 1.22474487139158904910;
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[3], D = params[4], A = params[5], nexp = params[6], K = params[7];
+    T const Ie = xi[6], alpha = xi[7], alpha_old = xi_prev[7];
+    Tens3<T> const zeta = sym6(xi);
+    Tens3<T> const bt = be_bar_trial(g);
+    Tens3<T> const s = scale(mu, zeta);
+    T const s_mag = norm(s);
+    double const power_law_offset = 1e-12;
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha))) + A * c8_pow(alpha + power_law_offset, nexp) + K * alpha;
+    T const f = (s_mag - sqrt_23 * sigma_yield) / val(mu);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    Tens3<T> Rz = zeta - dev(bt);
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = sqrt_32 * (alpha - alpha_old);
+      T const c = (2. * dgam) * Ie / s_mag;
+      Rz = Rz + scale(c, s);
+      Tens3<T> be = zeta;
+      be.xx = be.xx + Ie; be.yy = be.yy + Ie; be.zz = be.zz + Ie;
+      R[6] = det(be) - 1.;
+      R[7] = f;
+    } else {
+      R[6] = Ie - trace(bt) / 3.;
+      R[7] = alpha - alpha_old;
+    }
+    pack_sym6(Rz, R);
+    return path;
+  }
+};
+
+// ---- mechanics.cpp: stabilised mixed u-p weak form, as point fluxes ----------
+// ip set 0 (mechanics.cpp:116-145, :169-213):
+//   R_u[n,i] += sum_j P_ij dN_n/dx_j w dv            P = sigma (small strain) or sigma cof(F)
+//   R_p[n]   -= (sigma_h/kappa) N_n w dv + sum_ij S_ij dp/dx_j dN_n/dx_i w dv,  S = tau I [cof^T cof / det F]
+// ip set 1 (:215-223):
+//   R_p[n]   -= (p/kappa) N_n w dv
+template <class T> struct MechFlux {
+  Tens3<T> Gu;  // multiplies grad N in the momentum residual
+  T Vp;         // multiplies N in the pressure residual
+  T Gp[3];      // multiplies grad N in the pressure residual
+};
+
+struct Mechanics {
+  template <class T, class Local>
+  C8_HD static void flux_coupled(Local const& local, PointState<T> const& g, double h, double stab_mult, MechFlux<T>& f) {
+    Tens3<T> stress = local.cauchy(g);
+    T const mu = compute_mu(local.params[0], local.params[1]);
+    T const psf = local.pressure_scale_factor();
+    T const tau = (stab_mult * 0.5 * h * h) / mu;  // mechanics.cpp:197
+    f.Vp = -(local.hydro_cauchy(g) / psf);
+    if (Local::FINITE_DEF) {
+      Tens3<T> const F = g.grad_u + eye3<T>();
+      Tens3<T> const C = cofactor(F);
+      T const detF = det(F);
+      stress = matmul(stress, C);  // PK1 = sigma cof(F)  (:133)
+      Tens3<T> const S = scale(tau / detF, matmul(transpose(C), C));  // :198-202
+      f.Gp[0] = -(S.xx * g.grad_p[0] + S.xy * g.grad_p[1] + S.xz * g.grad_p[2]);
+      f.Gp[1] = -(S.yx * g.grad_p[0] + S.yy * g.grad_p[1] + S.yz * g.grad_p[2]);
+      f.Gp[2] = -(S.zx * g.grad_p[0] + S.zy * g.grad_p[1] + S.zz * g.grad_p[2]);
+    } else {
+      f.Gp[0] = -(tau * g.grad_p[0]);
+      f.Gp[1] = -(tau * g.grad_p[1]);
+      f.Gp[2] = -(tau * g.grad_p[2]);
+    }
+    f.Gu = stress;
+  }
+  template <class T, class Local>
+  C8_HD static T flux_pressure(Local const& local, PointState<T> const& g) {  // :215-223
+    return -(g.p / local.pressure_scale_factor());
+  }
+};
+
+}  // namespace c8

@@ -1,0 +1,54 @@
+"""Synthetic meshes and prescribed fields for tests and the bench."""
+import numpy as np
+
+
+def brick(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
+    """Structured hex8 brick, x-fastest node numbering, standard hex8 node order."""
+    xs, ys, zs = np.linspace(0, lx, nx + 1), np.linspace(0, ly, ny + 1), np.linspace(0, lz, nz + 1)
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    nid = lambda i, j, k: (k * (ny + 1) + j) * (nx + 1) + i
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    conn = np.stack([nid(i, j, k), nid(i + 1, j, k), nid(i + 1, j + 1, k), nid(i, j + 1, k),
+                     nid(i, j, k + 1), nid(i + 1, j, k + 1), nid(i + 1, j + 1, k + 1), nid(i, j + 1, k + 1)],
+                    axis=1).astype(np.int32)
+    tol = 1e-12
+    sets = {
+        "xmin": np.where(coords[:, 0] < tol)[0], "xmax": np.where(coords[:, 0] > lx - tol)[0],
+        "ymin": np.where(coords[:, 1] < tol)[0], "ymax": np.where(coords[:, 1] > ly - tol)[0],
+        "zmin": np.where(coords[:, 2] < tol)[0], "zmax": np.where(coords[:, 2] > lz - tol)[0],
+    }
+    return coords, conn, sets
+
+
+def jiggle(coords, sets, amp, seed=7):
+    """Perturb interior nodes so elements are not parallelepipeds (exercises the full Jacobian)."""
+    rng = np.random.default_rng(seed)
+    c = coords.copy()
+    bnd = np.zeros(len(c), dtype=bool)
+    for v in sets.values():
+        bnd[v] = True
+    c[~bnd] += amp * (rng.random((int((~bnd).sum()), 3)) - 0.5)
+    return c
+
+
+def prescribed_fields(coords, eps_bar, E=1000.0, nu=0.25, seed=1234, ramp=False, perturb=1e-4):
+    """Prescribed displacement/pressure state of SURVEY.md section 8d: uniaxial stretch along y with a
+    lateral contraction, plus a small random perturbation (numpy default_rng(seed)).  With
+    ramp=True the stretch grows linearly with y so that part of the bar is plastic."""
+    rng = np.random.default_rng(seed)
+    x, y, z = coords[:, 0], coords[:, 1], coords[:, 2]
+    ly = max(y.max(), 1e-300)
+    e = eps_bar * (y / ly if ramp else 1.0)
+    u = np.zeros_like(coords)
+    if ramp:
+        u[:, 1] = 0.5 * eps_bar * y * y / ly
+    else:
+        u[:, 1] = eps_bar * y
+    u[:, 0] = -nu * e * x
+    u[:, 2] = -nu * e * z
+    u += perturb * eps_bar * (rng.random(coords.shape) - 0.5)
+    kappa = E / (3 * (1 - 2 * nu))
+    p = -kappa * (1 - 2 * nu) * e + perturb * eps_bar * kappa * (rng.random(len(coords)) - 0.5)
+    return np.ascontiguousarray(u.ravel()), np.ascontiguousarray(p)
