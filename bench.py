@@ -1,0 +1,162 @@
+"""bench.py -- element Jacobian assemblies / second on synthetic hex8 J2-plasticity bricks.
+
+One "step" = one pass of the hot path (c8_assemble_forward_jacobian: residual + Jacobian with the
+local return-mapping solves and the CSR scatter) over the rank's mesh part, inputs resident in HBM.
+Workload (BASELINE.json metric: "1M hex8 J2-plasticity fp64"): a 100x100x100 hex8 brick per GPU,
+small_J2 (E 1000, nu 0.25, K 100, Y 2), prescribed mixed elastic/plastic state of SURVEY.md 8d.
+For N > 1 the element partitions are independent (weak scaling: one 100^3 part per rank, which is
+what an 8-way block split of an 8M brick gives each GPU); the assembly has no data-path collective,
+only the barrier + max-over-ranks timing.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+
+
+def algorithmic_bytes(nelems, nnodes, nnz_total, nen=8, nqp=8, nloc=7, ndofn=4):
+    """every datum once. connectivity + xi_prev read + xi write; coords + x + x_prev read
+    + R write; each CSR value written once."""
+    return nelems * (4 * nen + 8 * nqp * nloc * 2) + nnodes * 8 * (3 + 2 * ndofn + ndofn) + 8 * nnz_total
+
+
+def cpu_baseline(n, nthreads):
+    """Oracle (CPU restatement of the reference algorithm) timed on an n^3 sample of the same workload."""
+    import oracle_lib as ol
+    from meshes import brick, prescribed_fields
+    c, conn, _ = brick(n, n, n)
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+    u, p = prescribed_fields(c, 0.004, ramp=True)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    ls, xi = orc.new_linsys(), orc.new_state()
+    t0 = time.perf_counter()
+    rc = orc.forward_jacobian(u, p, z, zp, orc.new_state(), xi, ls, nthreads=nthreads)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return len(conn) / dt, orc, (u, p, z, zp), ls, xi
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=100, help="brick edge (elements) per GPU")
+    ap.add_argument("--scatter", default="colored", choices=["colored", "atomic"])
+    ap.add_argument("--cpu-sample", type=int, default=24, help="edge of the CPU-baseline sample brick")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from calibr8_amd import Assembler, brick_mesh
+    from meshes import prescribed_fields
+
+    n = args.n
+    coords, conn = brick_mesh(n, n, n)
+    asm = Assembler(8, coords, conn, "small_J2", J2, device=str(dev), scatter=args.scatter)
+    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
+    xi_prev, xi = asm.new_state(), asm.new_state()
+    ls = asm.new_linsys()
+    asm.set_async(True)
+
+    def step():
+        asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    assert asm.status() == 0
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert asm.status() == 0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    nelems_total = asm.nelems * world
+    value = nelems_total * args.steps / dt
+    plastic_frac = float((xi[:, :, 6] > 0).double().mean().item())
+
+    out = {
+        "metric": "element Jacobian assemblies/sec, 1M hex8 J2-plasticity fp64",
+        "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d hex8 brick per GPU (%d elements, %d nodes), small_J2 E1000 nu0.25 K100 Y2, "
+                               "prescribed ramped uniaxial state eps=0.004 seed 1234, residual+Jacobian assembly"
+                               % (n, n, n, asm.nelems, asm.nnodes),
+                   "elements_per_gpu": asm.nelems, "plastic_fraction": plastic_frac, "scatter": args.scatter,
+                   "colors": asm.ncolors, "parallelism": "element partition per GPU, no data-path collective"},
+    }
+    if rank == 0:
+        nnz_total = sum(asm.nnz[i][j] for i in range(2) for j in range(2))
+        balg = algorithmic_bytes(asm.nelems, asm.nnodes, nnz_total)
+        achieved = balg / (kernel_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
+                           "kernel": "k_forward_jacobian<hex8,small_J2> (%d launches per step)"
+                                     % (asm.ncolors if args.scatter == "colored" else 1)}
+        if not args.no_cpu:
+            nthreads = 1
+            v, orc, (cu, cp, cz, czp), ls_o, xi_o = cpu_baseline(args.cpu_sample, nthreads)
+            out["cpu_baseline"] = {"value": v, "unit": "elements/s", "cores": nthreads, "kind": "port",
+                                   "sample": "%d^3 hex8 brick (%d elements) of the same workload, oracle/libc8oracle.so, "
+                                             "g++ -O2" % (args.cpu_sample, args.cpu_sample ** 3)}
+            # parity gate on the sample: the same sub-problem through the HIP path
+            from gpu_backend import GpuBackend
+            from parity import compare_systems, rel_vec
+            g = GpuBackend(8, orc.coords, orc.conn, "small_J2", J2, scatter=args.scatter)
+            ls_g, xi_g = g.new_linsys(), g.new_state()
+            assert g.forward_jacobian(cu, cp, cz, czp, g.new_state(), xi_g, ls_g) == 0
+            errs = compare_systems(orc, ls_g, ls_o)
+            errs["xi"] = rel_vec(xi_g, xi_o)
+            out["parity_max_rel_err"] = max(errs.values())
+            out["speedup_vs_cpu_baseline"] = value / v
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

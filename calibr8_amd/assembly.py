@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's evaluation interface for the hot path.
+
+`Assembler` plays the role of the (State, Disc) pair the reference's `eval_*` functions
+take (evaluations.hpp:23-84): it owns the discretisation tables through a c8_ctx and
+exposes one method per entry point with the same meaning and error behaviour
+(0 / -1 for a failed local solve; everything else raises).  All field arrays are torch
+float64 tensors resident in HBM; nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+
+NUM_PARAMS = {"elastic": 4, "small_J2": 6, "hyper_J2": 8}
+NEQ = (3, 1)
+
+
+def brick_mesh(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
+    """Structured hex8 brick (SURVEY.md section 8d synthetic meshes): coords [N,3], conn [E,8]."""
+    L = _l.load_library()
+    coords = np.zeros(((nx + 1) * (ny + 1) * (nz + 1), 3))
+    conn = np.zeros((nx * ny * nz, 8), dtype=np.int32)
+    _l.check(L.c8_brick_mesh(nx, ny, nz, lx, ly, lz, coords.ctypes.data_as(_l.dp), conn.ctypes.data_as(_l.i32p)))
+    return coords, conn
+
+
+def brick_partition(nx, ny, nz, px, py, pz):
+    L = _l.load_library()
+    part = np.zeros(nx * ny * nz, dtype=np.int32)
+    _l.check(L.c8_brick_partition(nx, ny, nz, px, py, pz, part.ctypes.data_as(_l.i32p)))
+    return part
+
+
+class LinearSystem:
+    """A[i][j] CSR values and b[i] in GHOST distribution, as device tensors (la->A, la->b)."""
+
+    def __init__(self, asm):
+        import torch
+        self.A = [[torch.zeros(asm.nnz[i][j], dtype=torch.float64, device=asm.device) for j in range(2)]
+                  for i in range(2)]
+        self.b = [torch.zeros(asm.nnodes * NEQ[i], dtype=torch.float64, device=asm.device) for i in range(2)]
+
+    def zero(self):  # la->zero_all(), primal.cpp:98
+        for i in range(2):
+            self.b[i].zero_()
+            for j in range(2):
+                self.A[i][j].zero_()
+
+    def c_struct(self):
+        s = _l.System()
+        for i in range(2):
+            s.b[i] = self.b[i].data_ptr()
+            for j in range(2):
+                s.A[i][j] = self.A[i][j].data_ptr()
+        return s
+
+
+class Assembler:
+    def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0, max_iters=500,
+                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter="colored"):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("calibr8_amd needs a HIP device: there is no CPU execution path")
+        self.L = _l.load_library()
+        self.torch = torch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.elem_type = int(elem_type)
+        self.nnodes, self.nelems, self.nn = self.coords.shape[0], self.conn.shape[0], self.conn.shape[1]
+        self.local_type = local_type
+        self.params = np.ascontiguousarray(np.atleast_2d(np.asarray(params, dtype=np.float64)))
+        self.nsets = self.params.shape[0]
+        self._es = None if elem_set is None else np.ascontiguousarray(elem_set, dtype=np.int32)
+        md = _l.MeshDesc(self.elem_type, self.nnodes, self.nelems, self.nsets, self.coords.ctypes.data_as(_l.dp),
+                         self.conn.ctypes.data_as(_l.i32p),
+                         self._es.ctypes.data_as(_l.i32p) if self._es is not None else None)
+        mo = _l.ModelDesc(b"mechanics", local_type.encode(), stab_mult, max_iters, abs_tol, rel_tol,
+                          self.params.shape[1], self.params.ctypes.data_as(_l.dp))
+        h = C.c_void_p()
+        _l.check(self.L.c8_create(C.byref(md), C.byref(mo), C.byref(h)))
+        self.h = h
+        self.nloc = self.L.c8_num_local_dofs(h)
+        self.npts = self.L.c8_num_local_points(h)
+        self.ncolors = self.L.c8_num_colors(h)
+        self.ndofs = 4 * self.nn
+        self.nnz = [[int(self.L.c8_graph_nnz(h, i, j)) for j in range(2)] for i in range(2)]
+        self._graph = None
+        self.set_scatter(scatter)
+        self.use_current_stream()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.c8_destroy(self.h)
+            self.h = None
+
+    # ---- discretisation ------------------------------------------------------------------
+    @property
+    def graph(self):
+        """(rowptr[i][j], colidx[i][j]) host arrays of the four CSR blocks."""
+        if self._graph is None:
+            rp = [[None, None], [None, None]]
+            ci = [[None, None], [None, None]]
+            for i in range(2):
+                for j in range(2):
+                    r = np.zeros(self.nnodes * NEQ[i] + 1, dtype=np.int64)
+                    c = np.zeros(self.nnz[i][j], dtype=np.int32)
+                    _l.check(self.L.c8_graph(self.h, i, j, r.ctypes.data_as(_l.i64p), c.ctypes.data_as(_l.i32p)))
+                    rp[i][j], ci[i][j] = r, c
+            self._graph = (rp, ci)
+        return self._graph
+
+    @property
+    def rowptr(self):
+        return self.graph[0]
+
+    @property
+    def colidx(self):
+        return self.graph[1]
+
+    def new_state(self):
+        xi = np.zeros((self.nelems, self.npts, self.nloc))
+        _l.check(self.L.c8_init_variables(self.h, xi.ctypes.data_as(_l.dp)))
+        return self.torch.from_numpy(xi).to(self.device)
+
+    def new_linsys(self):
+        return LinearSystem(self)
+
+    def dev(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    # ---- settings ----------------------------------------------------------------------------
+    def set_params(self, params):
+        self.params = np.ascontiguousarray(np.atleast_2d(np.asarray(params, dtype=np.float64)))
+        _l.check(self.L.c8_set_params(self.h, self.params.ctypes.data_as(_l.dp)))
+
+    def set_active(self, es, idx):
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        _l.check(self.L.c8_set_active_params(self.h, es, len(a), a.ctypes.data_as(_l.i32p)))
+
+    def set_scatter(self, mode):
+        m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC}[mode]
+        _l.check(self.L.c8_set_scatter_mode(self.h, m))
+
+    def set_async(self, flag):
+        _l.check(self.L.c8_set_async(self.h, int(flag)))
+
+    def use_current_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _l.check(self.L.c8_set_stream(self.h, C.c_void_p(s)))
+
+    def status(self):
+        rc = self.L.c8_status(self.h)
+        if rc < -1:
+            _l.check(rc)
+        return rc
+
+    # ---- the hot path --------------------------------------------------------------------------
+    @staticmethod
+    def _state(u, p, u_prev, p_prev, xi_prev, xi):
+        for t in (u, p, u_prev, p_prev, xi_prev, xi):
+            assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float64"
+        s = _l.State()
+        s.x[0], s.x[1] = u.data_ptr(), p.data_ptr()
+        s.x_prev[0], s.x_prev[1] = u_prev.data_ptr(), p_prev.data_ptr()
+        s.xi_prev, s.xi = xi_prev.data_ptr(), xi.data_ptr()
+        return s
+
+    def _rc(self, rc):
+        if rc < -1:
+            _l.check(rc)
+        return rc
+
+    def forward_jacobian(self, u, p, u_prev, p_prev, xi_prev, xi, ls):
+        """eval_forward_jacobian: returns 0, or -1 if a local Newton solve failed."""
+        st, sy = self._state(u, p, u_prev, p_prev, xi_prev, xi), ls.c_struct()
+        return self._rc(self.L.c8_assemble_forward_jacobian(self.h, C.byref(st), C.byref(sy)))
+
+    def global_residual(self, u, p, u_prev, p_prev, xi_prev, xi, ls):
+        st, sy = self._state(u, p, u_prev, p_prev, xi_prev, xi), ls.c_struct()
+        return self._rc(self.L.c8_assemble_residual(self.h, C.byref(st), C.byref(sy)))
+
+    def adjoint_jacobian(self, u, p, u_prev, p_prev, xi_prev, xi, g, f, ls):
+        st, sy = self._state(u, p, u_prev, p_prev, xi_prev, xi), ls.c_struct()
+        return self._rc(self.L.c8_assemble_adjoint_jacobian(self.h, C.byref(st), C.c_void_p(g.data_ptr()),
+                                                            C.c_void_p(f.data_ptr()), C.byref(sy)))
+
+    def solve_adjoint_local(self, u, p, u_prev, p_prev, xi_prev, xi, z_u, z_p, phi, g, f):
+        st = self._state(u, p, u_prev, p_prev, xi_prev, xi)
+        z = (C.c_void_p * 2)(z_u.data_ptr(), z_p.data_ptr())
+        return self._rc(self.L.c8_solve_adjoint_local(self.h, C.byref(st), z, C.c_void_p(phi.data_ptr()),
+                                                      C.c_void_p(g.data_ptr()), C.c_void_p(f.data_ptr())))
+
+    def qoi_gradient(self, u, p, u_prev, p_prev, xi_prev, xi, z_u, z_p, phi, grad):
+        st = self._state(u, p, u_prev, p_prev, xi_prev, xi)
+        z = (C.c_void_p * 2)(z_u.data_ptr(), z_p.data_ptr())
+        return self._rc(self.L.c8_param_gradient(self.h, C.byref(st), z, C.c_void_p(phi.data_ptr()),
+                                                 C.c_void_p(grad.data_ptr())))
+
+    def eval_qoi(self, u, p, J):
+        st = self._state(u, p, u, p, u, u)
+        return self._rc(self.L.c8_eval_qoi(self.h, C.byref(st), C.c_void_p(J.data_ptr())))

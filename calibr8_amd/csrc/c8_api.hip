@@ -1,0 +1,294 @@
+// c8_api.hip -- implementation of the C ABI in include/c8.h.
+//
+// The context owns the host tables (node graph, colouring) and their device mirrors;
+// every assembly call is a (colour-batched) sequence of kernel launches on the context's
+// stream.  There is no CPU execution path here: without a HIP device c8_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/c8.h"
+#include "c8_host.hpp"
+#include "c8_kernels.hpp"
+
+using namespace c8;
+
+static thread_local std::string g_last_error;
+static int fail(int code, std::string const& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define C8_HIP(call)                                                                               \
+  do {                                                                                             \
+    hipError_t err__ = (call);                                                                     \
+    if (err__ != hipSuccess) return fail(C8_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(err__)); \
+  } while (0)
+
+struct c8_ctx {
+  HostMesh mesh;
+  HostGraph graph;
+  std::vector<int32_t> order, color_off;
+  int model = MODEL_NONE;
+  int nloc = 0, nparams = 0, npts0 = 0;
+  ModelSettings ms{};
+  std::vector<double> params;
+  std::vector<std::vector<int32_t>> active;
+  KernelSet ks{};
+  // device mirrors
+  int32_t* d_conn = nullptr;
+  double* d_coords = nullptr;
+  int32_t* d_nodeptr = nullptr;
+  uint8_t* d_pos = nullptr;
+  int32_t* d_elem_set = nullptr;
+  int32_t* d_order = nullptr;
+  double* d_params = nullptr;
+  int* d_status = nullptr;
+  hipStream_t stream = nullptr;
+  int scatter_mode = C8_SCATTER_COLORED;
+  int async = 0;
+};
+
+template <class T> static int upload(T** dptr, std::vector<T> const& h) {
+  if (h.empty()) { *dptr = nullptr; return C8_OK; }
+  C8_HIP(hipMalloc((void**)dptr, h.size() * sizeof(T)));
+  C8_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return C8_OK;
+}
+
+static int model_id(char const* name, int* nloc, int* nparams) {
+  std::string const s = name ? name : "";
+  if (s == "elastic") { *nloc = Elastic<double>::NLOC; *nparams = Elastic<double>::NPARAMS; return MODEL_ELASTIC; }
+  if (s == "small_J2") { *nloc = SmallJ2<double>::NLOC; *nparams = SmallJ2<double>::NPARAMS; return MODEL_SMALL_J2; }
+  if (s == "hyper_J2") { *nloc = HyperJ2<double>::NLOC; *nparams = HyperJ2<double>::NPARAMS; return MODEL_HYPER_J2; }
+  return MODEL_NONE;
+}
+
+extern "C" {
+
+const char* c8_last_error(void) { return g_last_error.c_str(); }
+
+int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
+  if (!md || !mo || !out) return fail(C8_ERR_ARG, "c8_create: null argument");
+  *out = nullptr;
+  if (md->elem_type != C8_ELEM_TET4 && md->elem_type != C8_ELEM_HEX8)
+    return fail(C8_ERR_UNSUPPORTED, "c8_create: elem_type must be C8_ELEM_TET4 or C8_ELEM_HEX8");
+  if (md->num_nodes <= 0 || md->num_elems <= 0 || md->num_elem_sets <= 0 || !md->coords || !md->conn)
+    return fail(C8_ERR_ARG, "c8_create: empty mesh");
+  if (std::string(mo->global_type ? mo->global_type : "") != "mechanics")
+    return fail(C8_ERR_UNSUPPORTED, "c8_create: global residual must be 'mechanics' (mixed formulation)");
+  int nloc = 0, nparams = 0;
+  int const model = model_id(mo->local_type, &nloc, &nparams);
+  if (model == MODEL_NONE) return fail(C8_ERR_UNSUPPORTED, std::string("c8_create: unknown local residual name: ") + (mo->local_type ? mo->local_type : "(null)"));
+  if (mo->num_params != nparams || !mo->params) return fail(C8_ERR_ARG, "c8_create: wrong number of material parameters for this model");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(C8_ERR_DEVICE, "c8_create: no HIP device available (this library has no CPU path)");
+
+  c8_ctx* c = new c8_ctx();
+  c->mesh.elem_type = md->elem_type;
+  c->mesh.nn = md->elem_type;
+  c->mesh.nnodes = md->num_nodes;
+  c->mesh.nelems = md->num_elems;
+  c->mesh.nsets = md->num_elem_sets;
+  c->mesh.coords.assign(md->coords, md->coords + (size_t)md->num_nodes * 3);
+  c->mesh.conn.assign(md->conn, md->conn + (size_t)md->num_elems * c->mesh.nn);
+  if (md->elem_set) {
+    c->mesh.elem_set.assign(md->elem_set, md->elem_set + md->num_elems);
+    for (int32_t s : c->mesh.elem_set)
+      if (s < 0 || s >= md->num_elem_sets) { delete c; return fail(C8_ERR_ARG, "c8_create: elem_set id out of range"); }
+  } else if (md->num_elem_sets != 1) {
+    delete c;
+    return fail(C8_ERR_ARG, "c8_create: elem_set is required when num_elem_sets > 1");
+  }
+  std::string err = build_node_graph(c->mesh, c->graph);
+  if (err.empty()) err = color_elements(c->mesh, c->order, c->color_off);
+  if (!err.empty()) { delete c; return fail(C8_ERR_ARG, "c8_create: " + err); }
+  c->model = model;
+  c->nloc = nloc;
+  c->nparams = nparams;
+  c->npts0 = (md->elem_type == C8_ELEM_HEX8) ? Elem<C8_HEX8>::NP0 : Elem<C8_TET4>::NP0;
+  c->ms = ModelSettings{mo->stabilization_multiplier, mo->local_abs_tol, mo->local_rel_tol, mo->local_max_iters};
+  c->params.assign(mo->params, mo->params + (size_t)md->num_elem_sets * nparams);
+  c->active.assign(md->num_elem_sets, std::vector<int32_t>());
+  c->active[0].push_back(0);  // default: E of element set 0 (small_J2.cpp:96-98)
+  c->ks = get_kernels(md->elem_type, model);
+  int rc = C8_OK;
+  if ((rc = upload(&c->d_conn, c->mesh.conn)) || (rc = upload(&c->d_coords, c->mesh.coords)) ||
+      (rc = upload(&c->d_nodeptr, c->graph.nodeptr)) || (rc = upload(&c->d_pos, c->graph.pos)) ||
+      (rc = upload(&c->d_elem_set, c->mesh.elem_set)) || (rc = upload(&c->d_order, c->order)) ||
+      (rc = upload(&c->d_params, c->params))) {
+    c8_destroy(c);
+    return rc;
+  }
+  if (hipMalloc((void**)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
+    c8_destroy(c);
+    return fail(C8_ERR_DEVICE, "c8_create: status allocation failed");
+  }
+  *out = c;
+  return C8_OK;
+}
+
+void c8_destroy(c8_ctx* c) {
+  if (!c) return;
+  hipFree(c->d_conn); hipFree(c->d_coords); hipFree(c->d_nodeptr); hipFree(c->d_pos);
+  hipFree(c->d_elem_set); hipFree(c->d_order); hipFree(c->d_params); hipFree(c->d_status);
+  delete c;
+}
+
+int c8_num_local_dofs(const c8_ctx* c) { return c ? c->nloc : C8_ERR_ARG; }
+int c8_num_local_points(const c8_ctx* c) { return c ? c->npts0 : C8_ERR_ARG; }
+int c8_num_colors(const c8_ctx* c) { return c ? (int)c->color_off.size() - 1 : C8_ERR_ARG; }
+int64_t c8_graph_nnz(const c8_ctx* c, int i, int j) {
+  if (!c || i < 0 || i > 1 || j < 0 || j > 1) return C8_ERR_ARG;
+  return block_nnz(c->graph, c->mesh.nnodes, i, j);
+}
+int c8_graph(const c8_ctx* c, int i, int j, int64_t* rowptr, int32_t* colidx) {
+  if (!c || i < 0 || i > 1 || j < 0 || j > 1 || !rowptr || !colidx) return fail(C8_ERR_ARG, "c8_graph: bad argument");
+  block_csr(c->graph, c->mesh.nnodes, i, j, rowptr, colidx);
+  return C8_OK;
+}
+int c8_init_variables(const c8_ctx* c, double* xi) {
+  if (!c || !xi) return fail(C8_ERR_ARG, "c8_init_variables: bad argument");
+  size_t const npt = (size_t)c->mesh.nelems * c->npts0;
+  for (size_t q = 0; q < npt; ++q) {
+    double* x = xi + q * c->nloc;
+    if (c->model == MODEL_ELASTIC) Elastic<double>::init_variables(x);
+    else if (c->model == MODEL_SMALL_J2) SmallJ2<double>::init_variables(x);
+    else HyperJ2<double>::init_variables(x);
+  }
+  return C8_OK;
+}
+
+int c8_set_params(c8_ctx* c, const double* params) {
+  if (!c || !params) return fail(C8_ERR_ARG, "c8_set_params: bad argument");
+  c->params.assign(params, params + c->params.size());
+  C8_HIP(hipMemcpyAsync(c->d_params, c->params.data(), c->params.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  C8_HIP(hipStreamSynchronize(c->stream));
+  return C8_OK;
+}
+int c8_set_active_params(c8_ctx* c, int es, int n, const int32_t* idx) {
+  if (!c || es < 0 || es >= c->mesh.nsets || n < 0 || (n > 0 && !idx)) return fail(C8_ERR_ARG, "c8_set_active_params: bad argument");
+  for (int k = 0; k < n; ++k)
+    if (idx[k] < 0 || idx[k] >= c->nparams) return fail(C8_ERR_ARG, "c8_set_active_params: parameter index out of range");
+  c->active[es].assign(idx, idx + n);
+  return C8_OK;
+}
+int c8_num_active_params(const c8_ctx* c) {
+  if (!c) return C8_ERR_ARG;
+  int n = 0;
+  for (auto const& a : c->active) n += (int)a.size();
+  return n;
+}
+int c8_set_stream(c8_ctx* c, void* s) {
+  if (!c) return fail(C8_ERR_ARG, "c8_set_stream: null ctx");
+  c->stream = (hipStream_t)s;
+  return C8_OK;
+}
+int c8_set_scatter_mode(c8_ctx* c, int mode) {
+  if (!c || (mode != C8_SCATTER_ATOMIC && mode != C8_SCATTER_COLORED)) return fail(C8_ERR_ARG, "c8_set_scatter_mode: bad argument");
+  c->scatter_mode = mode;
+  return C8_OK;
+}
+int c8_set_async(c8_ctx* c, int async) {
+  if (!c) return fail(C8_ERR_ARG, "c8_set_async: null ctx");
+  c->async = async ? 1 : 0;
+  return C8_OK;
+}
+int c8_status(c8_ctx* c) {
+  if (!c) return fail(C8_ERR_ARG, "c8_status: null ctx");
+  int h = 0;
+  C8_HIP(hipMemcpyAsync(&h, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  C8_HIP(hipStreamSynchronize(c->stream));
+  if (h != 0) {
+    C8_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+    return fail(C8_LOCAL_SOLVE_FAILED, "a local constitutive Newton solve did not converge");
+  }
+  return C8_OK;
+}
+
+}  // extern "C"
+
+static MeshTables tables(c8_ctx const* c, bool colored) {
+  return MeshTables{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, colored ? c->d_order : nullptr, c->d_params};
+}
+
+// run one launcher over the whole mesh: one launch per colour, or one atomic launch
+static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, SystemArgs sa, char const* what) {
+  if (!fn) return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": not available for this element/model");
+  bool const colored = (c->scatter_mode == C8_SCATTER_COLORED);
+  sa.status = c->d_status;
+  sa.atomic = colored ? 0 : 1;
+  LaunchArgs a{tables(c, colored), c->ms, fa, sa, 0, 0, c->stream};
+  if (colored) {
+    int const nc = (int)c->color_off.size() - 1;
+    for (int k = 0; k < nc; ++k) {
+      a.first = c->color_off[k];
+      a.count = c->color_off[k + 1] - c->color_off[k];
+      C8_HIP(fn(a));
+    }
+  } else {
+    a.first = 0;
+    a.count = c->mesh.nelems;
+    C8_HIP(fn(a));
+  }
+  if (c->async) return C8_OK;
+  return c8_status(c);
+}
+
+static bool check_state(const c8_state* st) {
+  return st && st->x[0] && st->x[1] && st->x_prev[0] && st->x_prev[1] && st->xi_prev && st->xi;
+}
+static FieldArgs field_args(const c8_state* st) {
+  return FieldArgs{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
+}
+
+extern "C" {
+
+int c8_assemble_forward_jacobian(c8_ctx* c, const c8_state* st, const c8_system* sys) {
+  if (!c || !check_state(st) || !sys) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null argument");
+  for (int i = 0; i < 2; ++i) {
+    if (!sys->b[i]) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null b");
+    for (int j = 0; j < 2; ++j)
+      if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null A block");
+  }
+  SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
+  return run(c, c->ks.forward_jacobian, field_args(st), sa, "c8_assemble_forward_jacobian");
+}
+
+int c8_assemble_residual(c8_ctx* c, const c8_state*, const c8_system*) {
+  (void)c;
+  return fail(C8_ERR_UNSUPPORTED, "c8_assemble_residual: not implemented yet");
+}
+int c8_assemble_adjoint_jacobian(c8_ctx*, const c8_state*, double*, const double*, const c8_system*) {
+  return fail(C8_ERR_UNSUPPORTED, "c8_assemble_adjoint_jacobian: not implemented yet");
+}
+int c8_solve_adjoint_local(c8_ctx*, const c8_state*, const double* const*, double*, double*, double*) {
+  return fail(C8_ERR_UNSUPPORTED, "c8_solve_adjoint_local: not implemented yet");
+}
+int c8_param_gradient(c8_ctx*, const c8_state*, const double* const*, const double*, double*) {
+  return fail(C8_ERR_UNSUPPORTED, "c8_param_gradient: not implemented yet");
+}
+int c8_eval_qoi(c8_ctx*, const c8_state*, double*) {
+  return fail(C8_ERR_UNSUPPORTED, "c8_eval_qoi: not implemented yet");
+}
+
+int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, double* coords, int32_t* conn) {
+  if (nx <= 0 || ny <= 0 || nz <= 0 || !coords || !conn) return fail(C8_ERR_ARG, "c8_brick_mesh: bad argument");
+  HostMesh m;
+  make_brick(nx, ny, nz, lx, ly, lz, m);
+  std::memcpy(coords, m.coords.data(), m.coords.size() * sizeof(double));
+  std::memcpy(conn, m.conn.data(), m.conn.size() * sizeof(int32_t));
+  return C8_OK;
+}
+int c8_brick_partition(int nx, int ny, int nz, int px, int py, int pz, int32_t* elem_part) {
+  if (nx <= 0 || ny <= 0 || nz <= 0 || px <= 0 || py <= 0 || pz <= 0 || !elem_part) return fail(C8_ERR_ARG, "c8_brick_partition: bad argument");
+  std::vector<int32_t> part;
+  brick_partition(nx, ny, nz, px, py, pz, part);
+  std::memcpy(elem_part, part.data(), part.size() * sizeof(int32_t));
+  return C8_OK;
+}
+
+}  // extern "C"

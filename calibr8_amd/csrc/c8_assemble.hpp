@@ -83,10 +83,13 @@ template <class E, class SH> C8_HD void shape_entry(SH& sh, int ip_set, int pt, 
   E::point(ip_set, pt, xi, w);
   // J(a,b) = d x_b / d xi_a
   double J[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double g[3];
     E::dNdxi(n, xi, g);
+    C8_UNROLL
     for (int a = 0; a < 3; ++a)
+      C8_UNROLL
       for (int b = 0; b < 3; ++b) J[a][b] += g[a] * sh.X[n][b];
   }
   Tens3<double> Jt;
@@ -96,6 +99,7 @@ template <class E, class SH> C8_HD void shape_entry(SH& sh, int ip_set, int pt, 
   double const dJ = det(Jt);
   Tens3<double> const Ji = inverse(Jt);
   if (n0 == 0) sh.wdv[pt] = w * dJ;
+  C8_UNROLL
   for (int n = n0; n < n1; ++n) {
     double g[3];
     E::dNdxi(n, xi, g);
@@ -122,6 +126,7 @@ template <class E, class EX, class SH> C8_HD void shape_tables(EX& ex, SH& sh, i
 // mean-square edge length, mechanics.cpp:103-113
 template <class E, class SH> C8_HD double elem_size(SH const& sh) {
   double h = 0.;
+  C8_UNROLL
   for (int e = 0; e < E::NEDGES; ++e) {
     int a, b;
     E::edge(e, a, b);
@@ -139,9 +144,11 @@ C8_HD void interpolate_values(SH const& sh, int pt, PointState<T>& g) {
   double u[3] = {0., 0., 0.}, gu[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
   double p = 0., gp[3] = {0., 0., 0.};
   double gup[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double const Nn = sh.N[pt][n];
     double const d0 = sh.dN[pt][n][0], d1 = sh.dN[pt][n][1], d2 = sh.dN[pt][n][2];
+    C8_UNROLL
     for (int i = 0; i < 3; ++i) {
       double const un = sh.u[n][i];
       u[i] += un * Nn;
@@ -155,6 +162,7 @@ C8_HD void interpolate_values(SH const& sh, int pt, PointState<T>& g) {
     p += pn * Nn;
     gp[0] += pn * d0; gp[1] += pn * d1; gp[2] += pn * d2;
   }
+  C8_UNROLL
   for (int i = 0; i < 3; ++i) { g.u[i] = T(u[i]); g.grad_p[i] = T(gp[i]); }
   g.p = T(p);
   g.grad_u.xx = T(gu[0][0]); g.grad_u.xy = T(gu[0][1]); g.grad_u.xz = T(gu[0][2]);
@@ -187,9 +195,11 @@ template <class E, class SH> C8_HD void seed_x(SH const& sh, int pt, int k, Poin
   G.zx.d = (isu && eq == 2) ? d0 : 0.; G.zy.d = (isu && eq == 2) ? d1 : 0.; G.zz.d = (isu && eq == 2) ? d2 : 0.;
 }
 C8_HD void unseed(PointState<Dual>& g) {
+  C8_UNROLL
   for (int i = 0; i < 3; ++i) { g.u[i].d = 0.; g.grad_p[i].d = 0.; }
   g.p.d = 0.;
   Tens3<Dual>* t[2] = {&g.grad_u, &g.grad_u_prev};
+  C8_UNROLL
   for (int q = 0; q < 2; ++q) {
     t[q]->xx.d = 0.; t[q]->xy.d = 0.; t[q]->xz.d = 0.;
     t[q]->yx.d = 0.; t[q]->yy.d = 0.; t[q]->yz.d = 0.;
@@ -205,13 +215,16 @@ C8_HD void unseed(PointState<Dual>& g) {
 template <int NL, class EX, class SH, class GetB>
 C8_HD bool gj_solve(EX& ex, SH& sh, GetB getb) {
   bool ok = true;
+  C8_UNROLL
   for (int s = 0; s < NL; ++s) {
     ex.each([&](int k) {
       double* b = getb(k);
       double col[NL];
+      C8_UNROLL
       for (int r = 0; r < NL; ++r) col[r] = sh.M[r][s];
       int rstar = s;
       double big = fabs(col[s]);
+      C8_UNROLL
       for (int r = s + 1; r < NL; ++r) {
         double const a = fabs(col[r]);
         if (a > big) { big = a; rstar = r; }
@@ -220,18 +233,25 @@ C8_HD bool gj_solve(EX& ex, SH& sh, GetB getb) {
       // swap rows s <-> rstar in this lane's copies (compile-time slots, run-time rstar)
       double const cs = col[s], bs = b[s];
       double cpiv = cs, bpiv = bs;
-      for (int r = s + 1; r < NL; ++r) {
-        if (r == rstar) { cpiv = col[r]; bpiv = b[r]; col[r] = cs; b[r] = bs; }
-      }
+      static_for<NL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        bool const hit = (r > s) && (r == rstar);
+        cpiv = hit ? col[r] : cpiv;
+        bpiv = hit ? b[r] : bpiv;
+        col[r] = hit ? cs : col[r];
+        b[r] = hit ? bs : b[r];
+      });
       double const inv = 1. / cpiv;
       double const bsn = bpiv * inv;
       b[s] = bsn;
+      C8_UNROLL
       for (int r = 0; r < NL; ++r) if (r != s) b[r] -= col[r] * bsn;
       if (k > s && k < NL) {  // column owner updates M[:, k]
         double const ms = sh.M[s][k], mr = sh.M[rstar][k];
         sh.M[rstar][k] = ms;
         double const msn = mr * inv;
         sh.M[s][k] = msn;
+        C8_UNROLL
         for (int r = 0; r < NL; ++r) if (r != s) sh.M[r][k] -= col[r] * msn;
       }
     });
@@ -255,6 +275,7 @@ template <class E, template <class> class ModelT> struct ForwardLane {
 
 template <class Model> C8_HD void load_params(Model& m, MeshTables const& mt, int e) {
   int const es = mt.elem_set ? mt.elem_set[e] : 0;
+  C8_UNROLL
   for (int q = 0; q < Model::NPARAMS; ++q) m.params[q] = Dual(mt.params[es * Model::NPARAMS + q]);
 }
 
@@ -287,6 +308,7 @@ C8_HD void accumulate_coupled(SH const& sh, int pt, int k, MechFlux<Dual> const&
   double const wdv = sh.wdv[pt];
   int ik, nk, eqk;
   slot_to_dof<E>(k, ik, nk, eqk);
+  C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double const d0 = sh.dN[pt][n][0] * wdv, d1 = sh.dN[pt][n][1] * wdv, d2 = sh.dN[pt][n][2] * wdv;
     Jcol[3 * n + 0] += f.Gu.xx.d * d0 + f.Gu.xy.d * d1 + f.Gu.xz.d * d2;
@@ -317,6 +339,7 @@ C8_HD void scatter_lhs(EX& ex, SH const& sh, MeshTables const& mt, SystemArgs co
     slot_to_dof<E>(k, ik, nk, eqk);
     int const neqk = ik == 0 ? 3 : 1;
     uint8_t const* posk = mt.pos + ((size_t)e * E::NN + nk) * E::NN;  // pos[e][col node nk][row node]
+    C8_UNROLL
     for (int a = 0; a < E::NDOF; ++a) {
       int ia, na, eqa;
       slot_to_dof<E>(a, ia, na, eqa);
@@ -360,6 +383,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
   load_element<E>(ex, sh, mt, fa, e, PREV);
   ex.each([&](int k) {
     Lane& r = ex.lane(k);
+    C8_UNROLL
     for (int a = 0; a < E::NDOF; ++a) r.Jcol[a] = 0.;
     r.Rk = 0.;
     r.failed = false;
@@ -378,6 +402,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
         ex.each([&](int k) {
           Lane& r = ex.lane(k);
           interpolate_values<E, Dual, PREV>(sh, pt, r.g);
+          C8_UNROLL
           for (int j = 0; j < NL; ++j) {
             r.m.xi_prev[j] = Dual(fa.xi_prev[q + j]);
             r.m.xi[j] = Dual(fa.xi[q + j], (j == k) ? 1. : 0.);
@@ -395,12 +420,14 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
               if (!((r.iter <= ms.max_iters) && !r.converged)) return;
               r.m.evaluate(r.g, ms.abs_tol);
               double nrm = 0.;
+              C8_UNROLL
               for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
               double const R_norm = sqrt(nrm);
               if (r.iter == 1) r.R_norm_0 = R_norm;
               double const R_norm_rel = R_norm / r.R_norm_0;  // NaN on elastic points: the abs test decides
               if ((R_norm_rel < ms.rel_tol) || (R_norm < ms.abs_tol)) r.converged = true;
-              if (k < NL) for (int j = 0; j < NL; ++j) sh.M[j][k] = r.m.R[j].d;
+              if (k < NL) C8_UNROLL for (int j = 0; j < NL; ++j) sh.M[j][k] = r.m.R[j].d;
+              C8_UNROLL
               for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].v;
             });
             ex.sync();
@@ -409,6 +436,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
             ex.each([&](int k) {
               Lane& r = ex.lane(k);
               if (!ok) { r.failed = true; r.iter = ms.max_iters + 1; return; }
+              C8_UNROLL
               for (int j = 0; j < NL; ++j) r.m.xi[j].v += r.b[j];
               r.iter++;
             });
@@ -422,15 +450,16 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
         //     evaluate -> dC/dx; dxi/dx = -(dC/dxi)^-1 dC/dx  (evaluations.cpp:101-115) ---
         ex.each([&](int k) {
           Lane& r = ex.lane(k);
-          if (k < NL) {
-            double v = r.m.xi[0].v;
-            for (int j = 1; j < NL; ++j) if (j == k) v = r.m.xi[j].v;
-            fa.xi[q + k] = v;
+          if (k == 0) {  // values are replicated over the group: one lane stores them
+            C8_UNROLL
+            for (int j = 0; j < NL; ++j) fa.xi[q + j] = r.m.xi[j].v;
           }
+          C8_UNROLL
           for (int j = 0; j < NL; ++j) r.m.xi[j].d = 0.;
           seed_x<E>(sh, pt, k, r.g);
           if (Model::HAS_LOCAL) {
             r.m.evaluate(r.g, ms.abs_tol);
+            C8_UNROLL
             for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].d;
           }
         });
@@ -440,6 +469,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           ex.each([&](int k) {
             Lane& r = ex.lane(k);
             if (!ok) r.failed = true;
+            C8_UNROLL
             for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];  // local->seed_wrt_x(dxi_dx)
           });
         }
@@ -459,6 +489,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           double const wdv = sh.wdv[pt];
           int ik, nk, eqk;
           slot_to_dof<E>(k, ik, nk, eqk);
+          C8_UNROLL
           for (int n = 0; n < E::NN; ++n) r.Jcol[3 * E::NN + n] += Vp.d * (sh.N[pt][n] * wdv);
           if (ik == 1) r.Rk += Vp.v * (sh.N[pt][nk] * wdv);
         });

@@ -12,13 +12,33 @@
 
 #include <math.h>
 
+#include <type_traits>
+#include <utility>
+
 #if defined(__HIPCC__)
 #define C8_HD __host__ __device__ __forceinline__
 #else
 #define C8_HD inline
 #endif
+// every small fixed-trip loop must be fully unrolled on the GPU so that register
+// arrays are only ever indexed by compile-time constants (no scratch memory)
+#if defined(__clang__)
+#define C8_UNROLL _Pragma("unroll")
+#else
+#define C8_UNROLL
+#endif
 
 namespace c8 {
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>).  Used where a run-time
+// value is compared against the loop index, so that no optimisation pass can fold the
+// "search" loop back into a run-time index into a register array.
+template <class F, int... I> C8_HD void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> C8_HD void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 struct Dual {
   double v, d;

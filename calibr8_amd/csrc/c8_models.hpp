@@ -81,8 +81,9 @@ template <class T> struct SmallJ2 {
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   T params[NPARAMS];  // E nu K Y cte delta_T  (small_J2.cpp:70-75)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
-  C8_HD static void init_variables(double* xi0) { for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
   C8_HD void initial_guess(PointState<T> const&) {  // :127-135
+    C8_UNROLL
     for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(xi_prev[k]));
   }
   C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :266-277
@@ -122,6 +123,7 @@ template <class T> struct SmallJ2 {
       pack_sym6(Rp, R);
       R[6] = f;
     } else {
+      C8_UNROLL
       for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
     }
     return path;
@@ -135,6 +137,7 @@ template <class T> struct HyperJ2 {
   T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2.cpp:83-90)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // zeta(6), Ie, alpha
   C8_HD static void init_variables(double* xi0) {  // :119-134
+    C8_UNROLL
     for (int k = 0; k < NLOC; ++k) xi0[k] = 0.;
     xi0[6] = 1.;
   }
@@ -154,6 +157,7 @@ template <class T> struct HyperJ2 {
     Tens3<T> const z = dev(bt);
     T zv[6];
     pack_sym6(z, zv);
+    C8_UNROLL
     for (int k = 0; k < 6; ++k) set_val(xi[k], val(zv[k]));
     set_val(xi[6], val(trace(bt)) / 3.);
     set_val(xi[7], val(xi_prev[7]));

@@ -1,0 +1,92 @@
+"""ctypes binding of libc8.so: one declaration per entry point of include/c8.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libc8.so")
+
+C8_ELEM_TET4, C8_ELEM_HEX8 = 4, 8
+C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+C8_SCATTER_ATOMIC, C8_SCATTER_COLORED = 0, 1
+
+dp = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+
+class C8Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("c8 error %d: %s" % (code, msg))
+        self.code = code
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("elem_type", C.c_int32), ("num_nodes", C.c_int32), ("num_elems", C.c_int32),
+                ("num_elem_sets", C.c_int32), ("coords", dp), ("conn", i32p), ("elem_set", i32p)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("global_type", C.c_char_p), ("local_type", C.c_char_p), ("stabilization_multiplier", C.c_double),
+                ("local_max_iters", C.c_int32), ("local_abs_tol", C.c_double), ("local_rel_tol", C.c_double),
+                ("num_params", C.c_int32), ("params", dp)]
+
+
+class State(C.Structure):
+    _fields_ = [("x", C.c_void_p * 2), ("x_prev", C.c_void_p * 2), ("xi_prev", C.c_void_p), ("xi", C.c_void_p)]
+
+
+class System(C.Structure):
+    _fields_ = [("A", (C.c_void_p * 2) * 2), ("b", C.c_void_p * 2)]
+
+
+# every symbol include/c8.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("c8_create", C.c_int, [C.POINTER(MeshDesc), C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    ("c8_destroy", None, [C.c_void_p]),
+    ("c8_last_error", C.c_char_p, []),
+    ("c8_num_local_dofs", C.c_int, [C.c_void_p]),
+    ("c8_num_local_points", C.c_int, [C.c_void_p]),
+    ("c8_num_colors", C.c_int, [C.c_void_p]),
+    ("c8_graph_nnz", C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    ("c8_graph", C.c_int, [C.c_void_p, C.c_int, C.c_int, i64p, i32p]),
+    ("c8_init_variables", C.c_int, [C.c_void_p, dp]),
+    ("c8_set_params", C.c_int, [C.c_void_p, dp]),
+    ("c8_set_active_params", C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p]),
+    ("c8_num_active_params", C.c_int, [C.c_void_p]),
+    ("c8_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("c8_set_scatter_mode", C.c_int, [C.c_void_p, C.c_int]),
+    ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
+    ("c8_status", C.c_int, [C.c_void_p]),
+    ("c8_assemble_forward_jacobian", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),
+    ("c8_assemble_residual", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),
+    ("c8_assemble_adjoint_jacobian", C.c_int, [C.c_void_p, C.POINTER(State), C.c_void_p, C.c_void_p, C.POINTER(System)]),
+    ("c8_solve_adjoint_local", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("c8_param_gradient", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    ("c8_eval_qoi", C.c_int, [C.c_void_p, C.POINTER(State), C.c_void_p]),
+    ("c8_brick_mesh", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, i32p]),
+    ("c8_brick_partition", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libc8.so.  Raises if the HIP extension has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("calibr8_amd/libc8.so is missing: run `python -m calibr8_amd.build` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise C8Error(rc, load_library().c8_last_error().decode())
+    return rc

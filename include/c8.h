@@ -1,0 +1,141 @@
+/* c8.h -- C ABI of the MI355X assembly / adjoint-sensitivity path of CALIBR8.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one
+ * of the reference's `eval_*` free functions (source/calibr8/src/evaluations.hpp:23-84);
+ * the arrays it reads and writes are the raw arrays those functions reach through
+ * Tpetra / apf today:
+ *   nodal fields x[i]     disc->primal(step).global[i]          (evaluations.cpp:24-27)
+ *   point fields xi       disc->primal(step).local[model_form]  (apf IP fields)
+ *   A[i][j]               la->A[GHOST][i][j] local CSR `values` (global_residual.cpp:529-537)
+ *   b[i]                  la->b[GHOST][i]  get1dViewNonConst()  (global_residual.cpp:469)
+ * Residual index 0 = u (3 equations per node), 1 = p (1 equation per node):
+ * `mechanics` with the mixed formulation (mechanics.cpp:16-55).  Local row id of
+ * (node, eq) in block i is node*neq_i + eq (disc.cpp:263-265 get_dof).
+ *
+ * Conventions
+ *   - No exceptions, no C++ types.  Every function returns an int status:
+ *       C8_OK (0); C8_LOCAL_SOLVE_FAILED (-1) = some local Newton solve did not converge,
+ *       outputs undefined -- the reference's convention (evaluations.hpp:19,
+ *       evaluations.cpp:95-97); < -1 = API misuse or device error, see c8_last_error().
+ *   - c8_mesh_desc / c8_model_desc hold HOST pointers, copied at c8_create().
+ *   - c8_state / c8_system and all other array arguments of the assembly calls are
+ *     DEVICE pointers (HBM).  The caller owns them.
+ *   - Outputs A, b, grad are ACCUMULATED INTO (+=), like scatter_lhs/scatter_rhs
+ *     (global_residual.cpp:463-479,556-586); the caller zeroes first (primal.cpp:98).
+ *   - One in-flight call per ctx; different ctxs (different GPUs/streams) are independent.
+ */
+#ifndef C8_H
+#define C8_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct c8_ctx c8_ctx;
+
+enum { C8_ELEM_TET4 = 4, C8_ELEM_HEX8 = 8 };
+enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -3, C8_ERR_UNSUPPORTED = -4 };
+enum { C8_SCATTER_ATOMIC = 0, C8_SCATTER_COLORED = 1 };
+
+/* One mesh part (what Disc holds after loadMdsMesh, disc.cpp:31-39): all nodes that touch a
+ * local element, local (GHOST) numbering. */
+typedef struct {
+  int32_t elem_type;       /* C8_ELEM_TET4 (what the reference runs, disc.cpp:165) or C8_ELEM_HEX8 */
+  int32_t num_nodes;
+  int32_t num_elems;
+  int32_t num_elem_sets;   /* material blocks, disc->num_elem_sets() */
+  const double* coords;    /* [num_nodes][3] */
+  const int32_t* conn;     /* [num_elems][nodes per element], local node ids */
+  const int32_t* elem_set; /* [num_elems] element-set id, or NULL when num_elem_sets == 1 */
+} c8_mesh_desc;
+
+/* The `residuals:` block of a deck (global_residual.cpp:620-630, local_residual.cpp:893-933). */
+typedef struct {
+  const char* global_type;          /* "mechanics" (mixed u-p formulation) */
+  const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" */
+  double stabilization_multiplier;  /* mechanics.cpp:47 */
+  int32_t local_max_iters;          /* "nonlinear max iters" of the local residual */
+  double local_abs_tol;             /* "nonlinear absolute tol" */
+  double local_rel_tol;             /* "nonlinear relative tol" */
+  int32_t num_params;               /* elastic 4 (E nu cte delta_T), small_J2 6 (E nu K Y cte delta_T),
+                                       hyper_J2 8 (E nu Y S D A n K) */
+  const double* params;             /* [num_elem_sets][num_params] */
+} c8_model_desc;
+
+/* Primal state at one load step (DEVICE pointers). */
+typedef struct {
+  const double* x[2];      /* x[0] = u [num_nodes*3], x[1] = p [num_nodes]  at step n   */
+  const double* x_prev[2]; /* same at step n-1                                           */
+  const double* xi_prev;   /* [num_elems][c8_num_local_points][c8_num_local_dofs], step n-1 */
+  double* xi;              /* same at step n: written by the forward assembly, read by the others */
+} c8_state;
+
+/* Linear system in GHOST distribution (DEVICE pointers). */
+typedef struct {
+  double* A[2][2]; /* CSR values over the graphs reported by c8_graph() */
+  double* b[2];    /* b[0] [num_nodes*3], b[1] [num_nodes] */
+} c8_system;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* Builds host tables (node graph, element colouring) and their device mirrors on the current
+ * HIP device.  Replaces State::State + Disc::build_data for this path (state.cpp:33-46,
+ * disc.cpp:563-583). */
+int c8_create(const c8_mesh_desc* mesh, const c8_model_desc* model, c8_ctx** out);
+void c8_destroy(c8_ctx* ctx);
+const char* c8_last_error(void);
+
+/* ---- discretisation queries (host arrays) ------------------------------------------------ */
+int c8_num_local_dofs(const c8_ctx* ctx);    /* LocalResidual::num_dofs: 1 / 7 / 8 */
+int c8_num_local_points(const c8_ctx* ctx);  /* points of the local-state field per element */
+int c8_num_colors(const c8_ctx* ctx);
+/* Block (i,j) CSR graph = m_graphs[GHOST][i][j] (disc.cpp:356-387): sorted columns. */
+int64_t c8_graph_nnz(const c8_ctx* ctx, int i, int j);
+int c8_graph(const c8_ctx* ctx, int i, int j, int64_t* rowptr, int32_t* colidx);
+/* LocalResidual::init_variables (local_residual.cpp:35-74): initial local state, HOST array
+ * [num_elems][points][dofs]. */
+int c8_init_variables(const c8_ctx* ctx, double* xi_host);
+
+/* ---- run-time settings ------------------------------------------------------------------- */
+int c8_set_params(c8_ctx* ctx, const double* params_host); /* LocalResidual::set_params; [sets][num_params] */
+/* Active (differentiated) parameters of one element set, LocalResidual::m_active_indices
+ * (small_J2.cpp:96-98 default = {0}; objective.cpp:110-115 overrides from the inverse block). */
+int c8_set_active_params(c8_ctx* ctx, int elem_set, int n, const int32_t* param_idx);
+int c8_num_active_params(const c8_ctx* ctx); /* total over element sets = length of grad */
+int c8_set_stream(c8_ctx* ctx, void* hip_stream);
+int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_COLORED (default) or C8_SCATTER_ATOMIC */
+/* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
+ * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */
+int c8_set_async(c8_ctx* ctx, int async);
+int c8_status(c8_ctx* ctx);
+
+/* ---- the hot path (all array arguments are DEVICE pointers) --------------------------------- */
+/* eval_forward_jacobian (evaluations.cpp:12-154): R and dR/dx with the local state condensed;
+ * writes the converged local state to st->xi. */
+int c8_assemble_forward_jacobian(c8_ctx* ctx, const c8_state* st, const c8_system* sys);
+/* eval_global_residual (evaluations.cpp:156-259): R only, from the stored local state. */
+int c8_assemble_residual(c8_ctx* ctx, const c8_state* st, const c8_system* sys);
+/* eval_adjoint_jacobian (evaluations.cpp:349-526), QoI = "average displacement":
+ * A += (dR/dx total)^T, b += -dJ/dx + f + (dxi/dx)^T g, and g -= dJ/dxi in place.
+ * g [elems][points][local dofs], f [elems][points][element dofs]. */
+int c8_assemble_adjoint_jacobian(c8_ctx* ctx, const c8_state* st, double* g, const double* f, const c8_system* sys);
+/* solve_adjoint_local (evaluations.cpp:528-659): phi from the global adjoint z, then the
+ * history vectors f, g for the previous step (overwritten). */
+int c8_solve_adjoint_local(c8_ctx* ctx, const c8_state* st, const double* const z[2], double* phi, double* g, double* f);
+/* eval_qoi_gradient (evaluations.cpp:758-925): grad[c8_num_active_params] +=
+ * sum_e sum_pt (dC/dp)^T phi + dJ/dp + (dR/dp)^T z. */
+int c8_param_gradient(c8_ctx* ctx, const c8_state* st, const double* const z[2], const double* phi, double* grad);
+/* eval_qoi (evaluations.cpp:662-756), "average displacement" (avg_disp.cpp:16-33): *J += value. */
+int c8_eval_qoi(c8_ctx* ctx, const c8_state* st, double* J);
+
+/* ---- host helpers for synthetic problems -------------------------------- */
+/* Structured hex8 brick; coords [(nx+1)(ny+1)(nz+1)][3], conn [nx*ny*nz][8] (host arrays). */
+int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, double* coords, int32_t* conn);
+/* Block partition px*py*pz of that brick: part id per element (host array). */
+int c8_brick_partition(int nx, int ny, int nz, int px, int py, int pz, int32_t* elem_part);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C8_H */

@@ -1,0 +1,144 @@
+"""`-m gpu` parity tests: the HIP path, called through the C ABI (libc8.so), against the CPU
+oracle on the same seeded inputs.  Bar (BASELINE.json): residuals, every Jacobian entry and the
+updated local state within 1e-12 relative (metrics in parity.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from meshes import brick, jiggle, prescribed_fields
+from parity import compare_systems, rel_vec
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-12
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+HJ2 = [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0]
+EL = [1000.0, 0.25, 1e-3, 10.0]
+
+
+def hex_mesh(n=(6, 5, 4)):
+    c, conn, sets = brick(n[0], n[1], n[2], 1.0, 0.8, 0.7)
+    return jiggle(c, sets, 0.03), conn
+
+
+def tet_mesh():
+    d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
+    return np.array(d["coords"]), np.array(d["conn"], dtype=np.int32)
+
+
+def both(et, c, conn, model, params, scatter):
+    from gpu_backend import GpuBackend
+    return ol.Oracle(et, c, conn, model, params), GpuBackend(et, c, conn, model, params, scatter=scatter)
+
+
+def forward_pair(orc, gpu, u, p, up, pp, xi_prev):
+    ls_o, xi_o = orc.new_linsys(), orc.new_state()
+    assert orc.forward_jacobian(u, p, up, pp, xi_prev, xi_o, ls_o) == 0
+    ls_g, xi_g = gpu.new_linsys(), gpu.new_state()
+    assert gpu.forward_jacobian(u, p, up, pp, xi_prev, xi_g, ls_g) == 0
+    errs = compare_systems(orc, ls_g, ls_o)
+    errs["xi"] = rel_vec(xi_g, xi_o)
+    return errs, xi_o
+
+
+@pytest.mark.parametrize("scatter", ["colored", "atomic"])
+@pytest.mark.parametrize("mesh", ["hex8", "tet4"])
+@pytest.mark.parametrize("model,params,eps", [("small_J2", J2, 0.001), ("small_J2", J2, 0.004),
+                                              ("elastic", EL, 0.002), ("hyper_J2", HJ2, 0.004)])
+def test_forward_jacobian_matches_oracle(mesh, model, params, eps, scatter):
+    c, conn = hex_mesh() if mesh == "hex8" else tet_mesh()
+    et = ol.HEX8 if mesh == "hex8" else ol.TET4
+    orc, gpu = both(et, c, conn, model, params, scatter)
+    assert gpu.npts == orc.npts and gpu.nloc == orc.nloc
+    for i in range(2):
+        for j in range(2):
+            assert np.array_equal(gpu.rowptr[i][j], orc.rowptr[i][j])
+            assert np.array_equal(gpu.colidx[i][j], orc.colidx[i][j])
+    u, p = prescribed_fields(c, eps, ramp=True, perturb=5e-2)
+    u0, p0 = np.zeros_like(u), np.zeros_like(p)
+    errs, xi1 = forward_pair(orc, gpu, u, p, u0, p0, orc.new_state())
+    assert max(errs.values()) < TOL, errs
+    errs, xi2 = forward_pair(orc, gpu, 1.5 * u, 1.5 * p, u, p, xi1)
+    assert max(errs.values()) < TOL, errs
+    if model == "small_J2" and eps > 0.003:
+        assert (xi2[:, :, 6] > 0).mean() > 0.3
+
+
+def test_forward_jacobian_accumulates_into_outputs():
+    # outputs are += (global_residual.cpp:463-479, :556-586): assembling twice doubles them
+    c, conn = hex_mesh((3, 3, 3))
+    orc, gpu = both(ol.HEX8, c, conn, "small_J2", J2, "colored")
+    u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    ls1, ls2 = gpu.new_linsys(), gpu.new_linsys()
+    gpu.forward_jacobian(u, p, z, zp, gpu.new_state(), gpu.new_state(), ls1)
+    gpu.forward_jacobian(u, p, z, zp, gpu.new_state(), gpu.new_state(), ls2)
+    gpu.forward_jacobian(u, p, z, zp, gpu.new_state(), gpu.new_state(), ls2)
+    assert rel_vec(ls2.b[0], 2 * ls1.b[0]) < 1e-14 and rel_vec(ls2.A[0][0], 2 * ls1.A[0][0]) < 1e-14
+
+
+def test_local_solve_failure_returns_minus_one():
+    # one local Newton iteration is not enough on a plastic point: -1, like evaluations.cpp:95-97
+    from gpu_backend import GpuBackend
+    c, conn = hex_mesh((3, 3, 3))
+    gpu = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, max_iters=1)
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2, max_iters=1)
+    u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    assert orc.forward_jacobian(u, p, z, zp, orc.new_state(), orc.new_state(), orc.new_linsys()) == -1
+    assert gpu.forward_jacobian(u, p, z, zp, gpu.new_state(), gpu.new_state(), gpu.new_linsys()) == -1
+    # and the context recovers
+    ue, pe = prescribed_fields(c, 0.0005, perturb=5e-2)
+    assert gpu.forward_jacobian(ue, pe, z, zp, gpu.new_state(), gpu.new_state(), gpu.new_linsys()) == 0
+
+
+def test_cube_elastic_pin_through_gpu():
+    # reference regression primal/cube_elastic.yaml.in:40-41 reproduced with the HIP assembly
+    from fe_driver import Dbc, Primal
+    from gpu_backend import GpuBackend
+    d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
+    c, conn, ns = np.array(d["coords"]), np.array(d["conn"], dtype=np.int32), d["node_sets"]
+    gpu = GpuBackend(ol.TET4, c, conn, "elastic", EL)
+    orc = ol.Oracle(ol.TET4, c, conn, "elastic", EL)
+    gpu.eval_qoi = orc.eval_qoi  # QoI integration is not on the GPU path yet
+    dbcs = [Dbc(0, k, ns[s], lambda x, y, z, t: 0.0) for k, s in enumerate(["xmin", "ymin", "zmin"])]
+    pr = Primal(gpu, c, dbcs).solve(1)
+    assert abs(pr.qoi() / 5.00000000000000184e-3 - 1) < 1e-6
+
+
+def test_large_brick_properties():
+    # BASELINE-size behaviour through size-independent properties on a 40^3 brick (64k hex8):
+    # (1) colour-batched and atomic scatter agree to rounding, (2) J x matches a directional
+    # finite difference of R, (3) rigid translation of u leaves R unchanged (small strain).
+    from gpu_backend import GpuBackend
+    c, conn, sets = brick(40, 40, 40)
+    gc = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="colored")
+    ga = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="atomic")
+    u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    lc, la = gc.new_linsys(), ga.new_linsys()
+    xc, xa = gc.new_state(), ga.new_state()
+    assert gc.forward_jacobian(u, p, z, zp, gc.new_state(), xc, lc) == 0
+    assert ga.forward_jacobian(u, p, z, zp, ga.new_state(), xa, la) == 0
+    errs = compare_systems(gc, la, lc)
+    assert max(errs.values()) < 1e-13 and np.array_equal(xc, xa), errs
+    import scipy.sparse as sp
+    A00 = sp.csr_matrix((lc.A[0][0], gc.colidx[0][0], gc.rowptr[0][0]))
+    A10 = sp.csr_matrix((lc.A[1][0], gc.colidx[1][0], gc.rowptr[1][0]), shape=(len(p), len(u)))
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(len(u))
+    v /= np.abs(v).max()
+    h = 1e-7
+    lp, lm = gc.new_linsys(), gc.new_linsys()
+    gc.forward_jacobian(u + h * v, p, z, zp, gc.new_state(), gc.new_state(), lp)
+    gc.forward_jacobian(u - h * v, p, z, zp, gc.new_state(), gc.new_state(), lm)
+    fd_u, fd_p = (lp.b[0] - lm.b[0]) / (2 * h), (lp.b[1] - lm.b[1]) / (2 * h)
+    assert np.abs(A00 @ v - fd_u).max() < 1e-5 * np.abs(A00 @ v).max()
+    assert np.abs(A10 @ v - fd_p).max() < 1e-5 * np.abs(A10 @ v).max()
+    lt = gc.new_linsys()
+    shift = np.tile([0.3, -0.2, 0.1], len(p))
+    gc.forward_jacobian(u + shift, p, z, zp, gc.new_state(), gc.new_state(), lt)
+    assert rel_vec(lt.b[0], lc.b[0]) < 1e-12 and rel_vec(lt.A[0][0], lc.A[0][0]) < 1e-12
