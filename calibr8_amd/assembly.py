@@ -199,6 +199,12 @@ class Assembler:
         return self._rc(self.L.c8_param_gradient(self.h, C.byref(st), z, C.c_void_p(phi.data_ptr()),
                                                  C.c_void_p(grad.data_ptr())))
 
-    def eval_qoi(self, u, p, J):
-        st = self._state(u, p, u, p, u, u)
-        return self._rc(self.L.c8_eval_qoi(self.h, C.byref(st), C.c_void_p(J.data_ptr())))
+    def eval_qoi(self, u, p, J, xi_prev=None, xi=None):
+        """eval_qoi: J (1-element device tensor) += QoI value.  The local state is only needed by QoIs
+        that read it ("average displacement" does not)."""
+        s = _l.State()
+        s.x[0], s.x[1] = u.data_ptr(), p.data_ptr()
+        s.x_prev[0], s.x_prev[1] = u.data_ptr(), p.data_ptr()
+        s.xi_prev = xi_prev.data_ptr() if xi_prev is not None else None
+        s.xi = xi.data_ptr() if xi is not None else None
+        return self._rc(self.L.c8_eval_qoi(self.h, C.byref(s), C.c_void_p(J.data_ptr())))

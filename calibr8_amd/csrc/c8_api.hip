@@ -45,6 +45,7 @@ struct c8_ctx {
   int32_t* d_elem_set = nullptr;
   int32_t* d_order = nullptr;
   double* d_params = nullptr;
+  int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
   int* d_status = nullptr;
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
@@ -64,6 +65,21 @@ static int model_id(char const* name, int* nloc, int* nparams) {
   if (s == "small_J2") { *nloc = SmallJ2<double>::NLOC; *nparams = SmallJ2<double>::NPARAMS; return MODEL_SMALL_J2; }
   if (s == "hyper_J2") { *nloc = HyperJ2<double>::NLOC; *nparams = HyperJ2<double>::NPARAMS; return MODEL_HYPER_J2; }
   return MODEL_NONE;
+}
+
+static int upload_active(c8_ctx* c) {
+  std::vector<int32_t> tab((size_t)c->mesh.nsets * 10, 0);
+  int ofs = 0;
+  for (int es = 0; es < c->mesh.nsets; ++es) {
+    int const n = (int)c->active[es].size();
+    tab[(size_t)es * 10 + 0] = ofs;
+    tab[(size_t)es * 10 + 1] = n;
+    for (int k = 0; k < n; ++k) tab[(size_t)es * 10 + 2 + k] = c->active[es][k];
+    ofs += n;
+  }
+  if (!c->d_active) C8_HIP(hipMalloc((void**)&c->d_active, tab.size() * sizeof(int32_t)));
+  C8_HIP(hipMemcpy(c->d_active, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return C8_OK;
 }
 
 extern "C" {
@@ -119,7 +135,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   if ((rc = upload(&c->d_conn, c->mesh.conn)) || (rc = upload(&c->d_coords, c->mesh.coords)) ||
       (rc = upload(&c->d_nodeptr, c->graph.nodeptr)) || (rc = upload(&c->d_pos, c->graph.pos)) ||
       (rc = upload(&c->d_elem_set, c->mesh.elem_set)) || (rc = upload(&c->d_order, c->order)) ||
-      (rc = upload(&c->d_params, c->params))) {
+      (rc = upload(&c->d_params, c->params)) || (rc = upload_active(c))) {
     c8_destroy(c);
     return rc;
   }
@@ -134,7 +150,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
   hipFree(c->d_conn); hipFree(c->d_coords); hipFree(c->d_nodeptr); hipFree(c->d_pos);
-  hipFree(c->d_elem_set); hipFree(c->d_order); hipFree(c->d_params); hipFree(c->d_status);
+  hipFree(c->d_elem_set); hipFree(c->d_order); hipFree(c->d_params); hipFree(c->d_active); hipFree(c->d_status);
   delete c;
 }
 
@@ -173,8 +189,9 @@ int c8_set_active_params(c8_ctx* c, int es, int n, const int32_t* idx) {
   if (!c || es < 0 || es >= c->mesh.nsets || n < 0 || (n > 0 && !idx)) return fail(C8_ERR_ARG, "c8_set_active_params: bad argument");
   for (int k = 0; k < n; ++k)
     if (idx[k] < 0 || idx[k] >= c->nparams) return fail(C8_ERR_ARG, "c8_set_active_params: parameter index out of range");
+  if (n > 8) return fail(C8_ERR_ARG, "c8_set_active_params: at most 8 active parameters per element set");
   c->active[es].assign(idx, idx + n);
-  return C8_OK;
+  return upload_active(c);
 }
 int c8_num_active_params(const c8_ctx* c) {
   if (!c) return C8_ERR_ARG;
@@ -215,13 +232,14 @@ static MeshTables tables(c8_ctx const* c, bool colored) {
   return MeshTables{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, colored ? c->d_order : nullptr, c->d_params};
 }
 
-// run one launcher over the whole mesh: one launch per colour, or one atomic launch
-static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, SystemArgs sa, char const* what) {
+// run one launcher over the whole mesh: one launch per colour, or one atomic launch.
+// `scatters` = the kernel adds into shared A/b entries (needs colouring or atomics).
+static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& aa, SystemArgs sa, bool scatters, char const* what) {
   if (!fn) return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": not available for this element/model");
-  bool const colored = (c->scatter_mode == C8_SCATTER_COLORED);
+  bool const colored = scatters && (c->scatter_mode == C8_SCATTER_COLORED);
   sa.status = c->d_status;
   sa.atomic = colored ? 0 : 1;
-  LaunchArgs a{tables(c, colored), c->ms, fa, sa, 0, 0, c->stream};
+  LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
   if (colored) {
     int const nc = (int)c->color_off.size() - 1;
     for (int k = 0; k < nc; ++k) {
@@ -255,24 +273,44 @@ int c8_assemble_forward_jacobian(c8_ctx* c, const c8_state* st, const c8_system*
       if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null A block");
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
-  return run(c, c->ks.forward_jacobian, field_args(st), sa, "c8_assemble_forward_jacobian");
+  return run(c, c->ks.forward_jacobian, field_args(st), AdjointArgs{}, sa, true, "c8_assemble_forward_jacobian");
 }
 
-int c8_assemble_residual(c8_ctx* c, const c8_state*, const c8_system*) {
-  (void)c;
-  return fail(C8_ERR_UNSUPPORTED, "c8_assemble_residual: not implemented yet");
+int c8_assemble_residual(c8_ctx* c, const c8_state* st, const c8_system* sys) {
+  if (!c || !check_state(st) || !sys || !sys->b[0] || !sys->b[1]) return fail(C8_ERR_ARG, "c8_assemble_residual: null argument");
+  SystemArgs sa{{{nullptr, nullptr}, {nullptr, nullptr}}, {sys->b[0], sys->b[1]}, nullptr, 0};
+  return run(c, c->ks.residual, field_args(st), AdjointArgs{}, sa, true, "c8_assemble_residual");
 }
-int c8_assemble_adjoint_jacobian(c8_ctx*, const c8_state*, double*, const double*, const c8_system*) {
-  return fail(C8_ERR_UNSUPPORTED, "c8_assemble_adjoint_jacobian: not implemented yet");
+
+int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const double* f, const c8_system* sys) {
+  if (!c || !check_state(st) || !sys || !g || !f) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null argument");
+  for (int i = 0; i < 2; ++i) {
+    if (!sys->b[i]) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null b");
+    for (int j = 0; j < 2; ++j)
+      if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null A block");
+  }
+  SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
+  AdjointArgs aa{g, const_cast<double*>(f), nullptr, nullptr, nullptr, nullptr, c->d_active};
+  return run(c, c->ks.adjoint_jacobian, field_args(st), aa, sa, true, "c8_assemble_adjoint_jacobian");
 }
-int c8_solve_adjoint_local(c8_ctx*, const c8_state*, const double* const*, double*, double*, double*) {
-  return fail(C8_ERR_UNSUPPORTED, "c8_solve_adjoint_local: not implemented yet");
+
+int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[2], double* phi, double* g, double* f) {
+  if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !g || !f) return fail(C8_ERR_ARG, "c8_solve_adjoint_local: null argument");
+  AdjointArgs aa{g, f, z[0], z[1], phi, nullptr, c->d_active};
+  return run(c, c->ks.adjoint_local, field_args(st), aa, SystemArgs{}, false, "c8_solve_adjoint_local");
 }
-int c8_param_gradient(c8_ctx*, const c8_state*, const double* const*, const double*, double*) {
-  return fail(C8_ERR_UNSUPPORTED, "c8_param_gradient: not implemented yet");
+
+int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], const double* phi, double* grad) {
+  if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !grad) return fail(C8_ERR_ARG, "c8_param_gradient: null argument");
+  AdjointArgs aa{nullptr, nullptr, z[0], z[1], const_cast<double*>(phi), grad, c->d_active};
+  return run(c, c->ks.param_gradient, field_args(st), aa, SystemArgs{}, false, "c8_param_gradient");
 }
-int c8_eval_qoi(c8_ctx*, const c8_state*, double*) {
-  return fail(C8_ERR_UNSUPPORTED, "c8_eval_qoi: not implemented yet");
+
+int c8_eval_qoi(c8_ctx* c, const c8_state* st, double* J) {
+  if (!c || !st || !st->x[0] || !st->x[1] || !J) return fail(C8_ERR_ARG, "c8_eval_qoi: null argument");
+  FieldArgs fa{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
+  AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, J, c->d_active};
+  return run(c, c->ks.qoi, fa, aa, SystemArgs{}, false, "c8_eval_qoi");
 }
 
 int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, double* coords, int32_t* conn) {

@@ -55,6 +55,16 @@ struct FieldArgs {
   double const* xi_prev;  // [nelems][NP0][NLOC]
   double* xi;             // [nelems][NP0][NLOC]
 };
+// extra arguments of the adjoint kernels (K3-K6)
+struct AdjointArgs {
+  double* g;           // local history  [nelems][NP0][NLOC]   (adjoint.cpp:52-74)
+  double* f;           // global history [nelems][NP0][NDOF]
+  double const* z_u;   // global adjoint solution, u block [nnodes][3]
+  double const* z_p;   // p block [nnodes]
+  double* phi;         // local adjoint [nelems][NP0][NLOC]
+  double* out;         // grad [n_active] (K5) or J [1] (K6)
+  int32_t const* active;  // [nsets][2 + 8]: {offset into grad, n_active, param indices...}
+};
 struct SystemArgs {
   double* A[2][2];  // CSR values of the four blocks
   double* b[2];     // residual vectors
@@ -72,6 +82,8 @@ template <class E, int NL> struct GroupShared {
   double dN[NPT][E::NN][3];
   double wdv[NPT];
   double M[NL][NL + 1];
+  double vec[NL + 1];      // right-hand side / history exchange between lanes
+  double z[E::NDOF];       // element adjoint solution (gather_adjoint, global_residual.cpp:423-438)
   double h;
   int32_t node[E::NN];
   int32_t nptr[E::NN], deg[E::NN];

@@ -4,7 +4,7 @@
 // cooperation is wave-synchronous through LDS (in-order per wave) with compiler fences.
 #include <hip/hip_runtime.h>
 
-#include "c8_assemble.hpp"
+#include "c8_assemble_adjoint.hpp"
 #include "c8_kernels.hpp"
 
 namespace c8 {
@@ -66,14 +66,142 @@ static hipError_t launch_forward(LaunchArgs const& a) {
   return hipGetLastError();
 }
 
-template <class E> static KernelSet kernel_set_for(int model) {
-  KernelSet ks{};
-  switch (model) {
-    case MODEL_ELASTIC: ks.forward_jacobian = &launch_forward<E, Elastic>; break;
-    case MODEL_SMALL_J2: ks.forward_jacobian = &launch_forward<E, SmallJ2>; break;
-    case MODEL_HYPER_J2: ks.forward_jacobian = &launch_forward<E, HyperJ2>; break;
-  }
+// group index -> element for the colour-batched / atomic element-parallel kernels
+#define C8_GROUP_PROLOGUE(E)                                                  \
+  constexpr int GPB = BLOCK / E::NDOF;                                        \
+  int const lb = xcd_block(blockIdx.x, nblocks);                              \
+  if (lb >= nblocks) return;                                                  \
+  int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;           \
+  int const gi = lb * GPB + gib;                                              \
+  if (gi >= count) return;                                                    \
+  int const e = mt.order ? mt.order[first + gi] : first + gi;
+
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_residual(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+                                                  int first, int count, int nblocks) {
+  C8_GROUP_PROLOGUE(E)
+  using Lane = ResidualLane<E, ModelT>;
+  __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
+  Lane L;
+  GpuExec<Lane> ex(k, L);
+  residual_element<E, ModelT>(ex, shs[gib], mt, ms, fa, sa, e);
+}
+
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_adjoint_jacobian(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+                                                          SystemArgs sa, int first, int count, int nblocks) {
+  C8_GROUP_PROLOGUE(E)
+  using Lane = AdjointLane<E, ModelT>;
+  __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
+  Lane L;
+  GpuExec<Lane> ex(k, L);
+  adjoint_jacobian_element<E, ModelT, AvgDisp>(ex, shs[gib], mt, ms, fa, aa, sa, e);
+}
+
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_adjoint_local(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+                                                       SystemArgs sa, int first, int count, int nblocks) {
+  C8_GROUP_PROLOGUE(E)
+  using Lane = AdjointLane<E, ModelT>;
+  __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
+  Lane L;
+  GpuExec<Lane> ex(k, L);
+  adjoint_local_element<E, ModelT>(ex, shs[gib], mt, ms, fa, aa, sa, e);
+}
+
+// K5/K6: each group walks the elements with a grid stride and adds its sums once at the end
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_param_gradient(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
+  constexpr int GPB = BLOCK / E::NDOF;
+  using Lane = GradLane<E, ModelT>;
+  __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
+  int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;
+  Lane L;
+  L.slot = -1;
+  L.acc = 0.;
+  GpuExec<Lane> ex(k, L);
+  for (int e = blockIdx.x * GPB + gib; e < count; e += gridDim.x * GPB)
+    param_gradient_element<E, ModelT, AvgDisp>(ex, shs[gib], mt, ms, fa, aa, e);
+  param_gradient_flush(ex, aa);
+}
+
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_qoi(MeshTables mt, FieldArgs fa, AdjointArgs aa, int count) {
+  constexpr int GPB = BLOCK / E::NDOF;
+  using Lane = QoiLane<E, ModelT>;
+  __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
+  int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;
+  Lane L;
+  L.acc = 0.;
+  GpuExec<Lane> ex(k, L);
+  for (int e = blockIdx.x * GPB + gib; e < count; e += gridDim.x * GPB)
+    qoi_element<E, ModelT, AvgDisp>(ex, shs[gib], mt, fa, e);
+  qoi_flush<E>(ex, aa.out);
+}
+
+template <class E> static void grid_for(LaunchArgs const& a, int& nblocks, int& grid) {
+  constexpr int GPB = BLOCK / E::NDOF;
+  nblocks = (a.count + GPB - 1) / GPB;
+  grid = ((nblocks + 7) / 8) * 8;
+}
+
+template <class E, template <class> class ModelT> static hipError_t launch_residual(LaunchArgs const& a) {
+  int nblocks, grid;
+  grid_for<E>(a, nblocks, grid);
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_residual<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa, a.first, a.count, nblocks);
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT> static hipError_t launch_adjoint_jacobian(LaunchArgs const& a) {
+  int nblocks, grid;
+  grid_for<E>(a, nblocks, grid);
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_adjoint_jacobian<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.sa, a.first, a.count, nblocks);
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local(LaunchArgs const& a) {
+  int nblocks, grid;
+  grid_for<E>(a, nblocks, grid);
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_adjoint_local<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.sa, a.first, a.count, nblocks);
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT> static hipError_t launch_param_gradient(LaunchArgs const& a) {
+  int nblocks, grid;
+  grid_for<E>(a, nblocks, grid);
+  if (a.count <= 0) return hipSuccess;
+  grid = nblocks < 2048 ? nblocks : 2048;
+  hipLaunchKernelGGL((k_param_gradient<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.count);
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT> static hipError_t launch_qoi(LaunchArgs const& a) {
+  int nblocks, grid;
+  grid_for<E>(a, nblocks, grid);
+  if (a.count <= 0) return hipSuccess;
+  grid = nblocks < 2048 ? nblocks : 2048;
+  hipLaunchKernelGGL((k_qoi<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.fa, a.aa, a.count);
+  return hipGetLastError();
+}
+
+template <class E, template <class> class ModelT> static KernelSet kernel_set() {
+  KernelSet ks;
+  ks.forward_jacobian = &launch_forward<E, ModelT>;
+  ks.residual = &launch_residual<E, ModelT>;
+  ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
+  ks.adjoint_local = &launch_adjoint_local<E, ModelT>;
+  ks.param_gradient = &launch_param_gradient<E, ModelT>;
+  ks.qoi = &launch_qoi<E, ModelT>;
   return ks;
+}
+
+// the registry: one line per constitutive model (local_residual.cpp:893-933)
+template <class E> static KernelSet kernel_set_for(int model) {
+  switch (model) {
+    case MODEL_ELASTIC: return kernel_set<E, Elastic>();
+    case MODEL_SMALL_J2: return kernel_set<E, SmallJ2>();
+    case MODEL_HYPER_J2: return kernel_set<E, HyperJ2>();
+  }
+  return KernelSet{};
 }
 
 KernelSet get_kernels(int elem_type, int model) {

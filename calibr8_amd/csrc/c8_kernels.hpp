@@ -3,7 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
-#include "c8_assemble.hpp"
+#include "c8_assemble_adjoint.hpp"
 
 namespace c8 {
 
@@ -13,6 +13,7 @@ struct LaunchArgs {
   MeshTables mt;
   ModelSettings ms;
   FieldArgs fa;
+  AdjointArgs aa;
   SystemArgs sa;
   int first, count;  // range of the element order to process
   hipStream_t stream;
@@ -21,7 +22,12 @@ struct LaunchArgs {
 typedef hipError_t (*LaunchFn)(LaunchArgs const&);
 
 struct KernelSet {
-  LaunchFn forward_jacobian;
+  LaunchFn forward_jacobian;   // K1, colour-batched or atomic
+  LaunchFn residual;           // K2
+  LaunchFn adjoint_jacobian;   // K3
+  LaunchFn adjoint_local;      // K4 (per-point outputs only: one launch, no colouring)
+  LaunchFn param_gradient;     // K5 (grid-stride, one atomic per lane at the end)
+  LaunchFn qoi;                // K6
 };
 
 // registry keyed like the reference's string factories

@@ -256,4 +256,16 @@ struct Mechanics {
   }
 };
 
+// ---- QoI concept (qoi.hpp): value_pt of the objective integrand at a point ---------------
+// "average displacement", avg_disp.cpp:16-33: J_pt = sum_i u_i w dv / ndims
+struct AvgDisp {
+  template <class T, class Local>
+  C8_HD static T evaluate(PointState<T> const& g, Local const&, double wdv) {
+    T v = g.u[0] * wdv;
+    v = v + g.u[1] * wdv;
+    v = v + g.u[2] * wdv;
+    return v / 3.;
+  }
+};
+
 }  // namespace c8

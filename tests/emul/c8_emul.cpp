@@ -1,16 +1,16 @@
 // tests/emul/c8_emul.cpp -- TEST INFRASTRUCTURE.
 //
-// Runs the product's kernel source (calibr8_amd/csrc/c8_assemble.hpp) on the CPU by
+// Runs the product's kernel source (calibr8_amd/csrc/c8_assemble*.hpp) on the CPU by
 // instantiating it with a serial executor: each() loops the lanes of one lane group,
 // shared (LDS) state is a stack object, atomics are plain adds.  This lets the CPU test
-// suite check the kernel algorithm against the oracle without a GPU.  It is not a
+// suite check the kernel algorithms against the oracle without a GPU.  It is not a
 // fallback: nothing under calibr8_amd/ can reach this file.
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
-#include "../../calibr8_amd/csrc/c8_assemble.hpp"
+#include "../../calibr8_amd/csrc/c8_assemble_adjoint.hpp"
 #include "../../calibr8_amd/csrc/c8_host.hpp"
 
 using namespace c8;
@@ -25,54 +25,86 @@ template <class Lane, int NDOF> struct CpuExec {
   void flag(int* s) { *s = 1; }
 };
 
-struct Problem {
-  HostMesh mesh;
-  HostGraph graph;
+enum { K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+
+struct Call {
+  int what;
+  int nelems;
   MeshTables mt;
   ModelSettings ms;
+  FieldArgs fa;
+  AdjointArgs aa;
+  SystemArgs sa;
 };
 
-template <class E, template <class> class ModelT>
-static void run_forward(Problem& pb, FieldArgs const& fa, SystemArgs const& sa) {
-  using Lane = ForwardLane<E, ModelT>;
-  auto* ex = new CpuExec<Lane, E::NDOF>();
-  GroupShared<E, ModelT<Dual>::NLOC> sh;
-  for (int e = 0; e < pb.mesh.nelems; ++e) forward_jacobian_element<E, ModelT>(*ex, sh, pb.mt, pb.ms, fa, sa, e);
-  delete ex;
+template <class E, template <class> class ModelT> static void run(Call const& c) {
+  using SH = GroupShared<E, ModelT<Dual>::NLOC>;
+  SH sh;
+  if (c.what == K_FORWARD) {
+    auto* ex = new CpuExec<ForwardLane<E, ModelT>, E::NDOF>();
+    for (int e = 0; e < c.nelems; ++e) forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, c.sa, e);
+    delete ex;
+  } else if (c.what == K_RESIDUAL) {
+    auto* ex = new CpuExec<ResidualLane<E, ModelT>, E::NDOF>();
+    for (int e = 0; e < c.nelems; ++e) residual_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, c.sa, e);
+    delete ex;
+  } else if (c.what == K_ADJ_JAC) {
+    auto* ex = new CpuExec<AdjointLane<E, ModelT>, E::NDOF>();
+    for (int e = 0; e < c.nelems; ++e) adjoint_jacobian_element<E, ModelT, AvgDisp>(*ex, sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+    delete ex;
+  } else if (c.what == K_ADJ_LOCAL) {
+    auto* ex = new CpuExec<AdjointLane<E, ModelT>, E::NDOF>();
+    for (int e = 0; e < c.nelems; ++e) adjoint_local_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+    delete ex;
+  } else if (c.what == K_GRAD) {
+    auto* ex = new CpuExec<GradLane<E, ModelT>, E::NDOF>();
+    for (int k = 0; k < E::NDOF; ++k) { ex->lanes[k].slot = -1; ex->lanes[k].acc = 0.; }
+    for (int e = 0; e < c.nelems; ++e) param_gradient_element<E, ModelT, AvgDisp>(*ex, sh, c.mt, c.ms, c.fa, c.aa, e);
+    param_gradient_flush(*ex, c.aa);
+    delete ex;
+  } else if (c.what == K_QOI) {
+    auto* ex = new CpuExec<QoiLane<E, ModelT>, E::NDOF>();
+    for (int k = 0; k < E::NDOF; ++k) ex->lanes[k].acc = 0.;
+    for (int e = 0; e < c.nelems; ++e) qoi_element<E, ModelT, AvgDisp>(*ex, sh, c.mt, c.fa, e);
+    qoi_flush<E>(*ex, c.aa.out);
+    delete ex;
+  }
 }
 
-template <class E> static int dispatch_forward(std::string const& model, Problem& pb, FieldArgs const& fa, SystemArgs const& sa) {
-  if (model == "elastic") run_forward<E, Elastic>(pb, fa, sa);
-  else if (model == "small_J2") run_forward<E, SmallJ2>(pb, fa, sa);
-  else if (model == "hyper_J2") run_forward<E, HyperJ2>(pb, fa, sa);
+template <class E> static int dispatch(std::string const& model, Call const& c) {
+  if (model == "elastic") run<E, Elastic>(c);
+  else if (model == "small_J2") run<E, SmallJ2>(c);
+  else if (model == "hyper_J2") run<E, HyperJ2>(c);
   else return -2;
   return 0;
 }
 
-extern "C" int c8emu_forward_jacobian(int elem_type, int nnodes, int nelems, double const* coords, int const* conn,
-                                      int const* elem_set, int nsets, char const* local_type, double stab_mult,
-                                      int max_iters, double abs_tol, double rel_tol, double const* params,
-                                      double const* u, double const* p, double const* u_prev, double const* p_prev,
-                                      double const* xi_prev, double* xi, double* A00, double* A01, double* A10,
-                                      double* A11, double* b0, double* b1) {
-  Problem pb;
-  pb.mesh.elem_type = elem_type;
-  pb.mesh.nn = elem_type;
-  pb.mesh.nnodes = nnodes;
-  pb.mesh.nelems = nelems;
-  pb.mesh.nsets = nsets;
-  pb.mesh.coords.assign(coords, coords + (size_t)nnodes * 3);
-  pb.mesh.conn.assign(conn, conn + (size_t)nelems * elem_type);
-  std::string const err = build_node_graph(pb.mesh, pb.graph);
+// ptrs: 0 u, 1 p, 2 u_prev, 3 p_prev, 4 xi_prev, 5 xi, 6..9 A00 A01 A10 A11, 10 b0, 11 b1,
+//       12 g, 13 f, 14 z_u, 15 z_p, 16 phi, 17 out
+extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, double const* coords, int const* conn,
+                          int const* elem_set, int nsets, char const* local_type, double stab_mult, int max_iters,
+                          double abs_tol, double rel_tol, double const* params, int const* active, double** ptrs) {
+  HostMesh mesh;
+  HostGraph graph;
+  mesh.elem_type = elem_type;
+  mesh.nn = elem_type;
+  mesh.nnodes = nnodes;
+  mesh.nelems = nelems;
+  mesh.nsets = nsets;
+  mesh.coords.assign(coords, coords + (size_t)nnodes * 3);
+  mesh.conn.assign(conn, conn + (size_t)nelems * elem_type);
+  std::string const err = build_node_graph(mesh, graph);
   if (!err.empty()) { std::fprintf(stderr, "c8emu: %s\n", err.c_str()); return -3; }
-  pb.mt = MeshTables{pb.mesh.conn.data(), pb.mesh.coords.data(), pb.graph.nodeptr.data(), pb.graph.pos.data(),
-                     elem_set, nullptr, params};
-  pb.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
-  FieldArgs fa{u, p, u_prev, p_prev, xi_prev, xi};
   int status = 0;
-  SystemArgs sa{{{A00, A01}, {A10, A11}}, {b0, b1}, &status, 0};
-  int rc = (elem_type == C8_HEX8) ? dispatch_forward<Elem<C8_HEX8>>(local_type, pb, fa, sa)
-                                  : dispatch_forward<Elem<C8_TET4>>(local_type, pb, fa, sa);
+  Call c;
+  c.what = what;
+  c.nelems = nelems;
+  c.mt = MeshTables{mesh.conn.data(), mesh.coords.data(), graph.nodeptr.data(), graph.pos.data(), elem_set, nullptr, params};
+  c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
+  c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
+  c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};
+  c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active};
+  int const rc = (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c);
   if (rc != 0) return rc;
   return status ? -1 : 0;
 }

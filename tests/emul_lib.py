@@ -1,15 +1,21 @@
-"""ctypes binding of tests/emul/libc8emul.so: the kernel source run on the CPU (TEST INFRASTRUCTURE)."""
+"""ctypes binding of tests/emul/libc8emul.so: the kernel source run on the CPU (TEST INFRASTRUCTURE).
+
+`Emul` has the same call shape as oracle_lib.Oracle so that the same tests and drivers run on the
+oracle, on the emulated kernels, and (gpu_backend.GpuBackend) on the HIP library."""
 import ctypes as C
 import os
 import subprocess
 
 import numpy as np
 
+import oracle_lib as ol
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMUL_DIR = os.path.join(HERE, "emul")
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
+K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI = 1, 2, 3, 4, 5, 6
 
 
 def lib():
@@ -17,24 +23,84 @@ def lib():
     if _lib is None:
         subprocess.check_call(["make", "-C", EMUL_DIR, "-s"])
         L = C.CDLL(os.path.join(EMUL_DIR, "libc8emul.so"))
-        L.c8emu_forward_jacobian.restype = C.c_int
-        L.c8emu_forward_jacobian.argtypes = [C.c_int, C.c_int, C.c_int, dp, ip, ip, C.c_int, C.c_char_p, C.c_double,
-                                             C.c_int, C.c_double, C.c_double, dp] + [dp] * 12
+        L.c8emu_call.restype = C.c_int
+        L.c8emu_call.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, ip, C.c_int, C.c_char_p, C.c_double,
+                                 C.c_int, C.c_double, C.c_double, dp, ip, C.POINTER(dp)]
         _lib = L
     return _lib
 
 
-def _d(a):
-    return a.ctypes.data_as(dp)
+class Emul:
+    def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0, max_iters=500,
+                 abs_tol=1e-12, rel_tol=1e-12):
+        # discretisation queries (graph, sizes, initial state) come from an Oracle object: test-side only
+        self.orc = ol.Oracle(elem_type, coords, conn, local_type, params, elem_set, stab_mult, max_iters, abs_tol,
+                             rel_tol)
+        o = self.orc
+        self.local_type, self.stab_mult = local_type, stab_mult
+        self.max_iters, self.abs_tol, self.rel_tol = max_iters, abs_tol, rel_tol
+        self.nnodes, self.nelems, self.nn, self.npts, self.nloc = o.nnodes, o.nelems, o.nn, o.npts, o.nloc
+        self.rowptr, self.colidx = o.rowptr, o.colidx
+        self.params = o.params
+        self.active = np.zeros((o.nsets, 10), dtype=np.int32)
+        self.set_active(0, [0])
 
+    def new_state(self):
+        return self.orc.new_state()
 
-def forward_jacobian(orc, u, p, u_prev, p_prev, xi_prev, xi, ls, local_type, stab_mult=1.0, max_iters=500,
-                     abs_tol=1e-12, rel_tol=1e-12):
-    """Same call shape as Oracle.forward_jacobian; mesh/params are taken from the Oracle object."""
-    L = lib()
-    es = orc._es.ctypes.data_as(ip) if orc._es is not None else None
-    return L.c8emu_forward_jacobian(orc.elem_type, orc.nnodes, orc.nelems, _d(orc.coords),
-                                    orc.conn.ctypes.data_as(ip), es, orc.nsets, local_type.encode(), stab_mult,
-                                    max_iters, abs_tol, rel_tol, _d(orc.params), _d(u), _d(p), _d(u_prev),
-                                    _d(p_prev), _d(xi_prev), _d(xi), _d(ls.A[0][0]), _d(ls.A[0][1]),
-                                    _d(ls.A[1][0]), _d(ls.A[1][1]), _d(ls.b[0]), _d(ls.b[1]))
+    def new_linsys(self):
+        return self.orc.new_linsys()
+
+    def set_params(self, p):
+        self.params = np.ascontiguousarray(np.atleast_2d(np.asarray(p, dtype=np.float64)))
+
+    def set_active(self, es, idx):
+        self.active[es, 1] = len(idx)
+        self.active[es, 2:2 + len(idx)] = idx
+        ofs = 0
+        for s in range(self.active.shape[0]):
+            self.active[s, 0] = ofs
+            ofs += self.active[s, 1]
+
+    def _call(self, what, ptrs):
+        o = self.orc
+        arr = (dp * 18)()
+        for k, a in ptrs.items():
+            arr[k] = a.ctypes.data_as(dp)
+        es = o._es.ctypes.data_as(ip) if o._es is not None else None
+        return lib().c8emu_call(what, o.elem_type, o.nnodes, o.nelems, o.coords.ctypes.data_as(dp),
+                                o.conn.ctypes.data_as(ip), es, o.nsets, self.local_type.encode(), self.stab_mult,
+                                self.max_iters, self.abs_tol, self.rel_tol, self.params.ctypes.data_as(dp),
+                                self.active.ctypes.data_as(ip), arr)
+
+    @staticmethod
+    def _fields(u, p, up, pp, xip, xi):
+        return {0: u, 1: p, 2: up, 3: pp, 4: xip, 5: xi}
+
+    @staticmethod
+    def _sys(ls):
+        return {6: ls.A[0][0], 7: ls.A[0][1], 8: ls.A[1][0], 9: ls.A[1][1], 10: ls.b[0], 11: ls.b[1]}
+
+    def forward_jacobian(self, u, p, up, pp, xip, xi, ls):
+        return self._call(K_FORWARD, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
+
+    def global_residual(self, u, p, up, pp, xip, xi, ls):
+        return self._call(K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
+
+    def adjoint_jacobian(self, u, p, up, pp, xip, xi, g, f, ls):
+        return self._call(K_ADJ_JAC, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls), 12: g, 13: f})
+
+    def solve_adjoint_local(self, u, p, up, pp, xip, xi, z_u, z_p, phi, g, f):
+        return self._call(K_ADJ_LOCAL, {**self._fields(u, p, up, pp, xip, xi), 12: g, 13: f, 14: z_u, 15: z_p,
+                                        16: phi})
+
+    def qoi_gradient(self, u, p, up, pp, xip, xi, z_u, z_p, phi, nparams):
+        grad = np.zeros(nparams)
+        self._call(K_GRAD, {**self._fields(u, p, up, pp, xip, xi), 14: z_u, 15: z_p, 16: phi, 17: grad})
+        return grad
+
+    def eval_qoi(self, u, p):
+        J = np.zeros(1)
+        xi = self.new_state()
+        self._call(K_QOI, {**self._fields(u, p, u, p, xi, xi), 17: J})
+        return float(J[0])

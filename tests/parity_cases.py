@@ -1,0 +1,109 @@
+"""Shared parity cases: the device-under-test (emulated kernels on the CPU, or the HIP library on a
+GPU) against the oracle on identical seeded inputs.  Each check feeds BOTH sides the oracle's
+inputs at every stage, so a deviation is attributed to the stage that produced it."""
+import json
+import os
+
+import numpy as np
+
+import oracle_lib as ol
+from meshes import brick, jiggle, prescribed_fields
+from parity import compare_systems, rel_vec
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+HJ2 = [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0]
+EL = [1000.0, 0.25, 1e-3, 10.0]
+CASES = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("elastic", EL, 0.002), ("hyper_J2", HJ2, 0.004)]
+MESHES = ["hex8", "tet4"]
+ACTIVE = {"small_J2": [0, 1, 2, 3], "elastic": [0, 1], "hyper_J2": [0, 1, 2, 3, 4, 7]}
+
+
+def mesh_of(kind, n=(4, 3, 3)):
+    if kind == "hex8":
+        c, conn, sets = brick(n[0], n[1], n[2], 1.0, 0.8, 0.7)
+        return ol.HEX8, jiggle(c, sets, 0.04), conn
+    d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
+    return ol.TET4, np.array(d["coords"]), np.array(d["conn"], dtype=np.int32)
+
+
+def make_pair(factory, kind, model, params, **kw):
+    et, c, conn = mesh_of(kind)
+    return ol.Oracle(et, c, conn, model, params, **kw), factory(et, c, conn, model, params, **kw), c
+
+
+def two_steps(orc, c, eps):
+    """Two consecutive load steps solved locally by the oracle: returns per-step (u, p, xi)."""
+    u1, p1 = prescribed_fields(c, eps, ramp=True, perturb=5e-2)
+    u0, p0 = np.zeros_like(u1), np.zeros_like(p1)
+    xi0, xi1, xi2 = orc.new_state(), orc.new_state(), orc.new_state()
+    assert orc.forward_jacobian(u1, p1, u0, p0, xi0, xi1, orc.new_linsys()) == 0
+    u2, p2 = 1.5 * u1, 1.5 * p1
+    assert orc.forward_jacobian(u2, p2, u1, p1, xi1, xi2, orc.new_linsys()) == 0
+    return [(u0, p0, xi0), (u1, p1, xi1), (u2, p2, xi2)]
+
+
+def check_forward(orc, dut, c, model, eps, tol):
+    st = two_steps(orc, c, eps)
+    for n in (1, 2):
+        (u, p, xi_ref), (up, pp, xip) = st[n], st[n - 1]
+        ls_o, ls_d = orc.new_linsys(), dut.new_linsys()
+        xo, xd = orc.new_state(), dut.new_state()
+        assert orc.forward_jacobian(u, p, up, pp, xip, xo, ls_o) == 0
+        assert dut.forward_jacobian(u, p, up, pp, xip, xd, ls_d) == 0
+        errs = compare_systems(orc, ls_d, ls_o)
+        errs["xi"] = rel_vec(xd, xo)
+        assert max(errs.values()) < tol, (n, errs)
+    if model == "small_J2" and eps > 0.003:
+        assert (st[2][2][:, :, 6] > 0).mean() > 0.3  # the plastic branch really ran
+
+
+def check_residual(orc, dut, c, eps, tol):
+    st = two_steps(orc, c, eps)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    ls_o, ls_d = orc.new_linsys(), dut.new_linsys()
+    orc.global_residual(u, p, up, pp, xip, xi, ls_o)
+    assert dut.global_residual(u, p, up, pp, xip, xi, ls_d) == 0
+    assert rel_vec(ls_d.b[0], ls_o.b[0]) < tol and rel_vec(ls_d.b[1], ls_o.b[1]) < tol
+    # the residual-only path reproduces the residual of the Jacobian path at the converged state
+    ls_j = orc.new_linsys()
+    orc.forward_jacobian(u, p, up, pp, xip, orc.new_state(), ls_j)
+    assert rel_vec(ls_d.b[0], ls_j.b[0]) < 1e-10 and rel_vec(ls_d.b[1], ls_j.b[1]) < 1e-10
+
+
+def check_adjoint_chain(orc, dut, c, model, eps, tol):
+    st = two_steps(orc, c, eps)
+    act = ACTIVE[model]
+    orc.set_active(0, act)
+    dut.set_active(0, act)
+    nd = 4 * orc.nn
+    rng = np.random.default_rng(11)
+    g_o = np.zeros((orc.nelems, orc.npts, orc.nloc))
+    f_o = np.zeros((orc.nelems, orc.npts, nd))
+    for n in (2, 1):
+        (u, p, xi), (up, pp, xip) = st[n], st[n - 1]
+        # K3
+        g_d, f_d = g_o.copy(), f_o.copy()
+        ls_o, ls_d = orc.new_linsys(), dut.new_linsys()
+        orc.adjoint_jacobian(u, p, up, pp, xip, xi, g_o, f_o, ls_o)
+        assert dut.adjoint_jacobian(u, p, up, pp, xip, xi, g_d, f_d, ls_d) == 0
+        errs = compare_systems(orc, ls_d, ls_o)
+        errs["g"] = rel_vec(g_d, g_o)
+        assert max(errs.values()) < tol, ("adjoint_jacobian", n, errs)
+        # a stand-in global adjoint solution (the linear solve is out of scope)
+        z_u = rng.standard_normal(len(u)) * 1e-3
+        z_p = rng.standard_normal(len(p)) * 1e-3
+        # K4
+        phi_o, phi_d = np.zeros_like(g_o), np.zeros_like(g_o)
+        g_d, f_d = g_o.copy(), f_o.copy()
+        orc.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi_o, g_o, f_o)
+        assert dut.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi_d, g_d, f_d) == 0
+        errs = {"phi": rel_vec(phi_d, phi_o), "g": rel_vec(g_d, g_o), "f": rel_vec(f_d, f_o)}
+        assert max(errs.values()) < tol, ("solve_adjoint_local", n, errs)
+        # K5
+        gr_o = orc.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
+        gr_d = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
+        scale = np.maximum(np.abs(gr_o), 1e-300)
+        assert (np.abs(gr_d - gr_o) / scale).max() < 1e-11, ("qoi_gradient", n, gr_d, gr_o)
+        # K6
+        assert abs(dut.eval_qoi(u, p) - orc.eval_qoi(u, p)) < tol * max(1.0, abs(orc.eval_qoi(u, p)))

@@ -10,13 +10,14 @@ import pytest
 import oracle_lib as ol
 from meshes import brick, jiggle, prescribed_fields
 from parity import compare_systems, rel_vec
+from parity_cases import EL, HJ2, J2
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-12
-J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
-HJ2 = [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0]
-EL = [1000.0, 0.25, 1e-3, 10.0]
+
+
+from parity_cases import CASES, MESHES, check_adjoint_chain, check_forward, check_residual, make_pair
 
 
 def hex_mesh(n=(6, 5, 4)):
@@ -24,47 +25,79 @@ def hex_mesh(n=(6, 5, 4)):
     return jiggle(c, sets, 0.03), conn
 
 
-def tet_mesh():
-    d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
-    return np.array(d["coords"]), np.array(d["conn"], dtype=np.int32)
-
-
 def both(et, c, conn, model, params, scatter):
     from gpu_backend import GpuBackend
     return ol.Oracle(et, c, conn, model, params), GpuBackend(et, c, conn, model, params, scatter=scatter)
 
 
-def forward_pair(orc, gpu, u, p, up, pp, xi_prev):
-    ls_o, xi_o = orc.new_linsys(), orc.new_state()
-    assert orc.forward_jacobian(u, p, up, pp, xi_prev, xi_o, ls_o) == 0
-    ls_g, xi_g = gpu.new_linsys(), gpu.new_state()
-    assert gpu.forward_jacobian(u, p, up, pp, xi_prev, xi_g, ls_g) == 0
-    errs = compare_systems(orc, ls_g, ls_o)
-    errs["xi"] = rel_vec(xi_g, xi_o)
-    return errs, xi_o
+def factory(scatter):
+    def make(et, c, conn, model, params, **kw):
+        from gpu_backend import GpuBackend
+        return GpuBackend(et, c, conn, model, params, scatter=scatter, **kw)
+    return make
 
 
 @pytest.mark.parametrize("scatter", ["colored", "atomic"])
-@pytest.mark.parametrize("mesh", ["hex8", "tet4"])
-@pytest.mark.parametrize("model,params,eps", [("small_J2", J2, 0.001), ("small_J2", J2, 0.004),
-                                              ("elastic", EL, 0.002), ("hyper_J2", HJ2, 0.004)])
+@pytest.mark.parametrize("mesh", MESHES)
+@pytest.mark.parametrize("model,params,eps", CASES)
 def test_forward_jacobian_matches_oracle(mesh, model, params, eps, scatter):
-    c, conn = hex_mesh() if mesh == "hex8" else tet_mesh()
-    et = ol.HEX8 if mesh == "hex8" else ol.TET4
-    orc, gpu = both(et, c, conn, model, params, scatter)
+    orc, gpu, c = make_pair(factory(scatter), mesh, model, params)
     assert gpu.npts == orc.npts and gpu.nloc == orc.nloc
     for i in range(2):
         for j in range(2):
             assert np.array_equal(gpu.rowptr[i][j], orc.rowptr[i][j])
             assert np.array_equal(gpu.colidx[i][j], orc.colidx[i][j])
-    u, p = prescribed_fields(c, eps, ramp=True, perturb=5e-2)
-    u0, p0 = np.zeros_like(u), np.zeros_like(p)
-    errs, xi1 = forward_pair(orc, gpu, u, p, u0, p0, orc.new_state())
-    assert max(errs.values()) < TOL, errs
-    errs, xi2 = forward_pair(orc, gpu, 1.5 * u, 1.5 * p, u, p, xi1)
-    assert max(errs.values()) < TOL, errs
-    if model == "small_J2" and eps > 0.003:
-        assert (xi2[:, :, 6] > 0).mean() > 0.3
+    check_forward(orc, gpu, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("mesh", MESHES)
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_residual_only_matches_oracle(mesh, model, params, eps):
+    orc, gpu, c = make_pair(factory("colored"), mesh, model, params)
+    check_residual(orc, gpu, c, eps, TOL)
+
+
+@pytest.mark.parametrize("scatter", ["colored", "atomic"])
+@pytest.mark.parametrize("mesh", MESHES)
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_adjoint_chain_matches_oracle(mesh, model, params, eps, scatter):
+    # eval_adjoint_jacobian -> solve_adjoint_local -> eval_qoi_gradient (+ eval_qoi), two steps
+    orc, gpu, c = make_pair(factory(scatter), mesh, model, params)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+
+
+def test_adjoint_gradient_fd_check_through_gpu():
+    # the reference's gradient check (main_inverse.cpp:126-158) with every assembly on the GPU
+    from fe_driver import Dbc, Primal, adjoint_gradient
+    from gpu_backend import GpuBackend
+    c, conn, sets = brick(3, 4, 3, 1.0, 1.5, 1.0)
+    c = jiggle(c, sets, 0.05)
+    z = lambda x, y, zz, t: 0.0
+    dbcs = [Dbc(0, 0, sets["ymin"], z), Dbc(0, 1, sets["ymin"], z), Dbc(0, 2, sets["ymin"], z),
+            Dbc(0, 1, sets["ymax"], lambda x, y, zz, t: 0.003 * t), Dbc(0, 0, sets["ymax"], z)]
+    base = np.array(J2)
+    act = [0, 1, 2, 3]
+
+    def objective(params):
+        be = GpuBackend(ol.HEX8, c, conn, "small_J2", params)
+        pr = Primal(be, c, dbcs, max_iters=15, abs_tol=1e-12, rel_tol=1e-12).solve(3)
+        return pr.qoi(), pr
+
+    J0, pr = objective(base)
+    assert pr.xi[-1][:, :, 6].max() > 1e-4
+    pr.be.set_active(0, act)
+    grad = adjoint_gradient(pr, len(act))
+    direction = np.array([100.0, 0.02, 10.0, 0.2])
+    gd = float(grad @ direction)
+    errs = []
+    for k in range(1, 8):
+        h = 10.0 ** (-k)
+        pp, pm = base.copy(), base.copy()
+        pp[act] += h * direction
+        pm[act] -= h * direction
+        errs.append(abs((objective(pp)[0] - objective(pm)[0]) / (2 * h) - gd))
+    errs = np.array(errs)
+    assert np.log10(errs.max() / errs.min()) > 5.0 and errs.min() < 1e-6 * abs(gd), (errs, gd)
 
 
 def test_forward_jacobian_accumulates_into_outputs():
@@ -102,8 +135,6 @@ def test_cube_elastic_pin_through_gpu():
     d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
     c, conn, ns = np.array(d["coords"]), np.array(d["conn"], dtype=np.int32), d["node_sets"]
     gpu = GpuBackend(ol.TET4, c, conn, "elastic", EL)
-    orc = ol.Oracle(ol.TET4, c, conn, "elastic", EL)
-    gpu.eval_qoi = orc.eval_qoi  # QoI integration is not on the GPU path yet
     dbcs = [Dbc(0, k, ns[s], lambda x, y, z, t: 0.0) for k, s in enumerate(["xmin", "ymin", "zmin"])]
     pr = Primal(gpu, c, dbcs).solve(1)
     assert abs(pr.qoi() / 5.00000000000000184e-3 - 1) < 1e-6
@@ -126,15 +157,21 @@ def test_large_brick_properties():
     errs = compare_systems(gc, la, lc)
     assert max(errs.values()) < 1e-13 and np.array_equal(xc, xa), errs
     import scipy.sparse as sp
-    A00 = sp.csr_matrix((lc.A[0][0], gc.colidx[0][0], gc.rowptr[0][0]))
-    A10 = sp.csr_matrix((lc.A[1][0], gc.colidx[1][0], gc.rowptr[1][0]), shape=(len(p), len(u)))
+    # the directional derivative is taken at an all-plastic state (no branch switches inside the
+    # finite-difference stencil; the elastic/plastic kink is not differentiable)
+    up, ppl = prescribed_fields(c, 0.008, ramp=False, perturb=1e-3)
+    lq, xq = gc.new_linsys(), gc.new_state()
+    assert gc.forward_jacobian(up, ppl, z, zp, gc.new_state(), xq, lq) == 0
+    assert (xq[:, :, 6] > 0).all()
+    A00 = sp.csr_matrix((lq.A[0][0], gc.colidx[0][0], gc.rowptr[0][0]))
+    A10 = sp.csr_matrix((lq.A[1][0], gc.colidx[1][0], gc.rowptr[1][0]), shape=(len(p), len(u)))
     rng = np.random.default_rng(5)
     v = rng.standard_normal(len(u))
     v /= np.abs(v).max()
     h = 1e-7
     lp, lm = gc.new_linsys(), gc.new_linsys()
-    gc.forward_jacobian(u + h * v, p, z, zp, gc.new_state(), gc.new_state(), lp)
-    gc.forward_jacobian(u - h * v, p, z, zp, gc.new_state(), gc.new_state(), lm)
+    gc.forward_jacobian(up + h * v, ppl, z, zp, gc.new_state(), gc.new_state(), lp)
+    gc.forward_jacobian(up - h * v, ppl, z, zp, gc.new_state(), gc.new_state(), lm)
     fd_u, fd_p = (lp.b[0] - lm.b[0]) / (2 * h), (lp.b[1] - lm.b[1]) / (2 * h)
     assert np.abs(A00 @ v - fd_u).max() < 1e-5 * np.abs(A00 @ v).max()
     assert np.abs(A10 @ v - fd_p).max() < 1e-5 * np.abs(A10 @ v).max()
