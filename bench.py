@@ -4,9 +4,10 @@ One "step" = one pass of the hot path (c8_assemble_forward_jacobian: residual + 
 local return-mapping solves and the CSR scatter) over the rank's mesh part, inputs resident in HBM.
 Workload (BASELINE.json metric: "1M hex8 J2-plasticity fp64"): a 100x100x100 hex8 brick per GPU,
 small_J2 (E 1000, nu 0.25, K 100, Y 2), prescribed mixed elastic/plastic state of SURVEY.md 8d.
-For N > 1 the element partitions are independent (weak scaling: one 100^3 part per rank, which is
-what an 8-way block split of an 8M brick gives each GPU); the assembly has no data-path collective,
-only the barrier + max-over-ranks timing.
+For N > 1 the workload is weak-scaled: rank r owns one 100^3 block of a (px*100, py*100, pz*100) brick
+(2x2x2 blocks of an 8M-element brick at N = 8, BASELINE.json config 5).  A step is then the assembly
+plus the owned/ghost halo ADD of the Jacobian and residual (LinearAlg::gather_A/gather_b) over RCCL;
+`value` = all elements of all ranks / max-over-ranks wall time.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
 Prints ONE JSON line on rank 0.
@@ -58,6 +59,8 @@ def main():
     ap.add_argument("--scatter", default="colored", choices=["colored", "atomic"])
     ap.add_argument("--cpu-sample", type=int, default=24, help="edge of the CPU-baseline sample brick")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path with all ranks on one GPU (halo staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -67,18 +70,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if args.backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    from calibr8_amd import Assembler, brick_mesh
+    from calibr8_amd import Assembler
+    from calibr8_amd import distributed as D
     from meshes import prescribed_fields
 
+    # mesh part of this rank: an n^3 block of the (px*n, py*n, pz*n) brick; element edge 1/n everywhere
     n = args.n
-    coords, conn = brick_mesh(n, n, n)
-    asm = Assembler(8, coords, conn, "small_J2", J2, device=str(dev), scatter=args.scatter)
-    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    pdims = D.pdims_for(world)
+    part = D.brick_part(rank, pdims, n, edge=1.0)
+    plan = D.HaloPlan(part, dist if world > 1 else None)
+    coords = plan.coords
+    asm = Assembler(8, coords, part.conn, "small_J2", J2, device=str(dev), scatter=args.scatter,
+                    extra_pairs=plan.extra_pairs)
+    halo = D.Halo(plan, asm.rowptr[0][0], asm.colidx[0][0], device=dev)
+    # prescribed state of SURVEY.md 8d on the rank's own block (local coordinates of the block)
+    origin = coords[: part.ntouched].min(axis=0)
+    u_h, p_h = prescribed_fields(coords - origin, 0.004, ramp=True, seed=1234 + rank)
     u, p = asm.dev(u_h), asm.dev(p_h)
     u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
     xi_prev, xi = asm.new_state(), asm.new_state()
@@ -86,7 +103,11 @@ def main():
     asm.set_async(True)
 
     def step():
+        # eval_forward_jacobian, then la->gather_A / gather_b (primal.cpp:99,110-111)
         asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+        if world > 1:
+            halo.gather_b(ls.b)
+            halo.gather_A(ls.A)
 
     def barrier():
         torch.cuda.synchronize()
@@ -101,14 +122,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for a, b in ev:
-        a.record()
-        step()
+        a.record()  # HIP events on the stream the kernels are launched on: assembly kernels only
+        asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
         b.record()
+        if world > 1:
+            halo.gather_b(ls.b)
+            halo.gather_A(ls.A)
     barrier()
     dt = time.perf_counter() - t0
     assert asm.status() == 0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -126,7 +150,10 @@ def main():
                                "prescribed ramped uniaxial state eps=0.004 seed 1234, residual+Jacobian assembly"
                                % (n, n, n, asm.nelems, asm.nnodes),
                    "elements_per_gpu": asm.nelems, "plastic_fraction": plastic_frac, "scatter": args.scatter,
-                   "colors": asm.ncolors, "parallelism": "element partition per GPU, no data-path collective"},
+                   "colors": asm.ncolors, "part_grid": list(pdims),
+                   "parallelism": "one n^3 element block per GPU; ghost rows of A and b ADDed into their owners "
+                                  "by one grouped neighbour all_to_all (RCCL) per step",
+                   "halo_bytes_per_step": int(halo.bytes_per_gather_A + halo.bytes_per_gather_b) if world > 1 else 0},
     }
     if rank == 0:
         nnz_total = sum(asm.nnz[i][j] for i in range(2) for j in range(2))
@@ -137,7 +164,7 @@ def main():
                            "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
                            "kernel": "k_forward_jacobian<hex8,small_J2> (%d launches per step)"
                                      % (asm.ncolors if args.scatter == "colored" else 1)}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             nthreads = 1
             v, orc, (cu, cp, cz, czp), ls_o, xi_o = cpu_baseline(args.cpu_sample, nthreads)
             out["cpu_baseline"] = {"value": v, "unit": "elements/s", "cores": nthreads, "kind": "port",
@@ -146,7 +173,7 @@ def main():
             # parity gate on the sample: the same sub-problem through the HIP path
             from gpu_backend import GpuBackend
             from parity import compare_systems, rel_vec
-            g = GpuBackend(8, orc.coords, orc.conn, "small_J2", J2, scatter=args.scatter)
+            g = GpuBackend(8, orc.coords, orc.conn, "small_J2", J2, scatter=args.scatter, device=str(dev))
             ls_g, xi_g = g.new_linsys(), g.new_state()
             assert g.forward_jacobian(cu, cp, cz, czp, g.new_state(), xi_g, ls_g) == 0
             errs = compare_systems(orc, ls_g, ls_o)

@@ -58,7 +58,7 @@ class LinearSystem:
 
 class Assembler:
     def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0, max_iters=500,
-                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter="colored"):
+                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter="colored", extra_pairs=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("calibr8_amd needs a HIP device: there is no CPU execution path")
@@ -74,9 +74,13 @@ class Assembler:
         self.params = np.ascontiguousarray(np.atleast_2d(np.asarray(params, dtype=np.float64)))
         self.nsets = self.params.shape[0]
         self._es = None if elem_set is None else np.ascontiguousarray(elem_set, dtype=np.int32)
+        self._xp = None if extra_pairs is None or len(extra_pairs) == 0 else \
+            np.ascontiguousarray(extra_pairs, dtype=np.int32).reshape(-1, 2)
         md = _l.MeshDesc(self.elem_type, self.nnodes, self.nelems, self.nsets, self.coords.ctypes.data_as(_l.dp),
                          self.conn.ctypes.data_as(_l.i32p),
-                         self._es.ctypes.data_as(_l.i32p) if self._es is not None else None)
+                         self._es.ctypes.data_as(_l.i32p) if self._es is not None else None,
+                         0 if self._xp is None else len(self._xp),
+                         None if self._xp is None else self._xp.ctypes.data_as(_l.i32p))
         mo = _l.ModelDesc(b"mechanics", local_type.encode(), stab_mult, max_iters, abs_tol, rel_tol,
                           self.params.shape[1], self.params.ctypes.data_as(_l.dp))
         h = C.c_void_p()

@@ -119,6 +119,10 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
     delete c;
     return fail(C8_ERR_ARG, "c8_create: elem_set is required when num_elem_sets > 1");
   }
+  if (md->num_extra_pairs > 0) {
+    if (!md->extra_pairs) { delete c; return fail(C8_ERR_ARG, "c8_create: extra_pairs is null"); }
+    c->mesh.extra_pairs.assign(md->extra_pairs, md->extra_pairs + (size_t)md->num_extra_pairs * 2);
+  }
   std::string err = build_node_graph(c->mesh, c->graph);
   if (err.empty()) err = color_elements(c->mesh, c->order, c->color_off);
   if (!err.empty()) { delete c; return fail(C8_ERR_ARG, "c8_create: " + err); }

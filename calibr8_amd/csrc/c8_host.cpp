@@ -16,6 +16,12 @@ std::string build_node_graph(HostMesh const& m, HostGraph& g) {
       if (na < 0 || na >= m.nnodes) return "connectivity entry out of range";
       cnt[(size_t)na + 1] += nn;
     }
+  size_t const nextra = m.extra_pairs.size() / 2;
+  for (size_t q = 0; q < nextra; ++q) {
+    int const r = m.extra_pairs[2 * q], c = m.extra_pairs[2 * q + 1];
+    if (r < 0 || r >= m.nnodes || c < 0 || c >= m.nnodes) return "extra graph pair out of range";
+    cnt[(size_t)r + 1] += 1;
+  }
   for (int n = 0; n < m.nnodes; ++n) cnt[n + 1] += cnt[n];
   std::vector<int32_t> raw((size_t)cnt[m.nnodes]);
   std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
@@ -24,6 +30,7 @@ std::string build_node_graph(HostMesh const& m, HostGraph& g) {
       int const na = m.conn[(size_t)e * nn + a];
       for (int b = 0; b < nn; ++b) raw[(size_t)fill[na]++] = m.conn[(size_t)e * nn + b];
     }
+  for (size_t q = 0; q < nextra; ++q) raw[(size_t)fill[m.extra_pairs[2 * q]]++] = m.extra_pairs[2 * q + 1];
   g.nodeptr.assign((size_t)m.nnodes + 1, 0);
   g.nodeadj.clear();
   g.nodeadj.reserve(raw.size() / 2);

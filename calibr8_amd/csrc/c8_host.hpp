@@ -20,6 +20,7 @@ struct HostMesh {
   std::vector<double> coords;     // [nnodes][3]
   std::vector<int32_t> conn;      // [nelems][nn]
   std::vector<int32_t> elem_set;  // [nelems] (empty = one set)
+  std::vector<int32_t> extra_pairs;  // [n][2] extra (row node, col node) graph entries
 };
 
 struct HostGraph {

@@ -22,7 +22,8 @@ class C8Error(RuntimeError):
 
 class MeshDesc(C.Structure):
     _fields_ = [("elem_type", C.c_int32), ("num_nodes", C.c_int32), ("num_elems", C.c_int32),
-                ("num_elem_sets", C.c_int32), ("coords", dp), ("conn", i32p), ("elem_set", i32p)]
+                ("num_elem_sets", C.c_int32), ("coords", dp), ("conn", i32p), ("elem_set", i32p),
+                ("num_extra_pairs", C.c_int32), ("extra_pairs", i32p)]
 
 
 class ModelDesc(C.Structure):

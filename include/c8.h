@@ -49,6 +49,12 @@ typedef struct {
   const double* coords;    /* [num_nodes][3] */
   const int32_t* conn;     /* [num_elems][nodes per element], local node ids */
   const int32_t* elem_set; /* [num_elems] element-set id, or NULL when num_elem_sets == 1 */
+  /* Extra (row node, col node) couplings to reserve in the graphs besides those of the local
+   * elements: on a multi-part mesh, the off-part columns of owned interface rows, so that the owned
+   * rows already have the union pattern of compute_owned_graph (disc.cpp:389-398) and the halo
+   * ADD of linear_alg.cpp:53-63 can land in place.  NULL / 0 on a single part. */
+  int32_t num_extra_pairs;
+  const int32_t* extra_pairs; /* [num_extra_pairs][2] */
 } c8_mesh_desc;
 
 /* The `residuals:` block of a deck (global_residual.cpp:620-630, local_residual.cpp:893-933). */

