@@ -137,6 +137,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    hb = torch.tensor([float(halo.bytes_per_gather_A + halo.bytes_per_gather_b) if world > 1 else 0.0],
+                      dtype=torch.float64, device=tmax.device)
+    if world > 1:
+        dist.all_reduce(hb, op=dist.ReduceOp.MAX)
+    halo_bytes = int(hb.item())
     nelems_total = asm.nelems * world
     value = nelems_total * args.steps / dt
     plastic_frac = float((xi[:, :, 6] > 0).double().mean().item())
@@ -153,7 +158,7 @@ def main():
                    "colors": asm.ncolors, "part_grid": list(pdims),
                    "parallelism": "one n^3 element block per GPU; ghost rows of A and b ADDed into their owners "
                                   "by one grouped neighbour all_to_all (RCCL) per step",
-                   "halo_bytes_per_step": int(halo.bytes_per_gather_A + halo.bytes_per_gather_b) if world > 1 else 0},
+                   "halo_send_bytes_per_step_max_rank": halo_bytes},
     }
     if rank == 0:
         nnz_total = sum(asm.nnz[i][j] for i in range(2) for j in range(2))

@@ -153,8 +153,8 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
 
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
-  hipFree(c->d_conn); hipFree(c->d_coords); hipFree(c->d_nodeptr); hipFree(c->d_pos);
-  hipFree(c->d_elem_set); hipFree(c->d_order); hipFree(c->d_params); hipFree(c->d_active); hipFree(c->d_status);
+  void* bufs[] = {c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
+  for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
 
