@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 def test_host_helpers_work_without_gpu():
     import calibr8_amd
     c, conn = calibr8_amd.brick_mesh(3, 2, 2, 3.0, 2.0, 2.0)
-    assert c.shape == (48, 3) and conn.shape == (12, 8)
-    assert np.allclose(c.max(0), [3, 2, 2]) and conn.max() == 47
+    assert c.shape == (36, 3) and conn.shape == (12, 8)
+    assert np.allclose(c.max(0), [3, 2, 2]) and conn.max() == 35
     from meshes import brick
     c2, conn2, _ = brick(3, 2, 2, 3.0, 2.0, 2.0)
     assert np.allclose(c, c2) and np.array_equal(conn, conn2)
