@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--edge", dest="n", type=int, default=100, help="brick edge (elements) per GPU")
     ap.add_argument("--scatter", default="colored", choices=["colored", "atomic"])
     ap.add_argument("--cpu-sample", type=int, default=24, help="edge of the CPU-baseline sample brick")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on one GPU (halo staged through the host)")
@@ -92,6 +93,7 @@ def main():
     coords = plan.coords
     asm = Assembler(8, coords, part.conn, "small_J2", J2, device=str(dev), scatter=args.scatter,
                     extra_pairs=plan.extra_pairs)
+    asm.set_kernel(args.kernel)
     halo = D.Halo(plan, asm.rowptr[0][0], asm.colidx[0][0], device=dev)
     # prescribed state of SURVEY.md 8d on the rank's own block (local coordinates of the block)
     origin = coords[: part.ntouched].min(axis=0)
@@ -154,7 +156,7 @@ def main():
         "config": {"workload": "%dx%dx%d hex8 brick per GPU (%d elements, %d nodes), small_J2 E1000 nu0.25 K100 Y2, "
                                "prescribed ramped uniaxial state eps=0.004 seed 1234, residual+Jacobian assembly"
                                % (n, n, n, asm.nelems, asm.nnodes),
-                   "elements_per_gpu": asm.nelems, "plastic_fraction": plastic_frac, "scatter": args.scatter,
+                   "elements_per_gpu": asm.nelems, "plastic_fraction": plastic_frac, "scatter": args.scatter, "kernel": args.kernel,
                    "colors": asm.ncolors, "part_grid": list(pdims),
                    "parallelism": "one n^3 element block per GPU; ghost rows of A and b ADDed into their owners "
                                   "by one grouped neighbour all_to_all (RCCL) per step",
@@ -167,7 +169,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                            "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
-                           "kernel": "k_forward_jacobian<hex8,small_J2> (%d launches per step)"
+                           "kernel": ("k_forward_jacobian" if args.kernel == "slot" else "k_forward_jacobian_wave") +
+                                     "<hex8,small_J2> (%d launches per step)"
                                      % (asm.ncolors if args.scatter == "colored" else 1)}
         if not args.no_cpu and world == 1:
             nthreads = 1

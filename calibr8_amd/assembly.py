@@ -148,6 +148,11 @@ class Assembler:
         m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC}[mode]
         _l.check(self.L.c8_set_scatter_mode(self.h, m))
 
+    def set_kernel(self, variant):
+        """'auto' | 'slot' (one lane group per element) | 'wave' (one wavefront per hex8 element)"""
+        v = {"auto": _l.C8_KERNEL_AUTO, "slot": _l.C8_KERNEL_SLOT, "wave": _l.C8_KERNEL_WAVE}[variant]
+        _l.check(self.L.c8_set_kernel_variant(self.h, v))
+
     def set_async(self, flag):
         _l.check(self.L.c8_set_async(self.h, int(flag)))
 

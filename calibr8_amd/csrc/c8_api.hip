@@ -49,6 +49,7 @@ struct c8_ctx {
   int* d_status = nullptr;
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
+  int kernel_variant = C8_KERNEL_AUTO;
   int async = 0;
 };
 
@@ -213,6 +214,13 @@ int c8_set_scatter_mode(c8_ctx* c, int mode) {
   c->scatter_mode = mode;
   return C8_OK;
 }
+int c8_set_kernel_variant(c8_ctx* c, int variant) {
+  if (!c || variant < C8_KERNEL_AUTO || variant > C8_KERNEL_WAVE) return fail(C8_ERR_ARG, "c8_set_kernel_variant: bad argument");
+  if (variant == C8_KERNEL_WAVE && !c->ks.forward_jacobian_wave)
+    return fail(C8_ERR_UNSUPPORTED, "c8_set_kernel_variant: the wave-per-element kernel needs hex8 elements");
+  c->kernel_variant = variant;
+  return C8_OK;
+}
 int c8_set_async(c8_ctx* c, int async) {
   if (!c) return fail(C8_ERR_ARG, "c8_set_async: null ctx");
   c->async = async ? 1 : 0;
@@ -277,7 +285,9 @@ int c8_assemble_forward_jacobian(c8_ctx* c, const c8_state* st, const c8_system*
       if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null A block");
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
-  return run(c, c->ks.forward_jacobian, field_args(st), AdjointArgs{}, sa, true, "c8_assemble_forward_jacobian");
+  LaunchFn fn = c->ks.forward_jacobian;
+  if (c->ks.forward_jacobian_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.forward_jacobian_wave;
+  return run(c, fn, field_args(st), AdjointArgs{}, sa, true, "c8_assemble_forward_jacobian");
 }
 
 int c8_assemble_residual(c8_ctx* c, const c8_state* st, const c8_system* sys) {

@@ -1,0 +1,399 @@
+// c8_assemble_wave.hpp -- K1 for hex8 with ONE WAVEFRONT PER ELEMENT.
+//
+// Same mathematics as forward_jacobian_element (c8_assemble.hpp, evaluations.cpp:12-154) but the
+// 64 lanes are re-assigned phase by phase so that every lane carries a useful tangent:
+//
+//   phase N  local Newton          lane = point*8 + xi-direction        all 8 coupled points at once
+//   phase D  point derivatives     lane = (point%4)*16 + q-direction    4 points per pass, 2 passes
+//            q = the 16 interpolated point quantities (grad u 9, p 1, grad p 3, u 3) that the
+//            residuals depend on; lane c gets dC/dq_c, solves dxi/dq_c, and column c of the
+//            13 x 16 matrix D = d(point fluxes)/dq with the local state condensed
+//   phase P  contraction           lane = column b (32) x row half (2)
+//            J_e += w dv  W^T D B   with B = dq/dx_e and W = d(R_e)/d(flux): the shape-function
+//            tables, both sparse (3-4 non-zeros per row/column)
+//
+// Against the slot-per-lane kernel this runs the expensive AD passes 2 (instead of 8) times
+// per element and the Newton iterations once (instead of 8 times), and needs no 32-entry
+// Jacobian column in registers while the constitutive code is live.  The chain rule through q
+// is exact: the result is the same dR/dx to rounding.
+//
+// Requires an element with 32 DOFs, 8 coupled points and identical point sets for both ip
+// sets (hex8): the two ip sets are fused by adding the pressure-mass flux to V_p.
+#pragma once
+
+#include "c8_assemble.hpp"
+
+namespace c8 {
+
+constexpr int WQ = 16;   // point quantities: grad_u (0..8 row-major), p (9), grad_p (10..12), u (13..15)
+constexpr int WF = 13;   // point fluxes: Gu (0..8 row-major), Vp (9), Gp (10..12)
+
+template <class E, int NL> struct WaveShared {
+  static constexpr int NLP = 8;  // lanes per point in phase N
+  double X[E::NN][3];
+  double u[E::NN][3], p[E::NN];
+  double u_prev[E::NN][3];
+  double N[E::NP0][E::NN];
+  double dN[E::NP0][E::NN][3];
+  double wdv[E::NP0];
+  double M[E::NP0][NLP][NLP + 1];   // dC/dxi per point
+  double q[E::NP0][WQ];             // interpolated values
+  double qprev[E::NP0][9];          // grad_u at the previous step (finite deformation)
+  double xi[E::NP0][NLP];           // converged local state
+  double xip[E::NP0][NLP];          // previous local state
+  double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
+  double F[E::NP0][WQ];             // flux values
+  double h;
+  int32_t node[E::NN];
+  int32_t nptr[E::NN], deg[E::NN];
+  int32_t failed;
+};
+
+template <template <class> class ModelT> struct WaveLane {
+  using Model = ModelT<Dual>;
+  Model m;
+  PointState<Dual> g;
+  double b[Model::NLOC];
+  double J[16];   // phase P: rows of this lane's half, column b
+  double R;
+  int iter;
+  double R_norm_0;
+  bool converged, failed;
+};
+
+template <class SH> C8_HD void load_point(SH const& sh, int pt, PointState<Dual>& g, bool prev) {
+  g.grad_u.xx = Dual(sh.q[pt][0]); g.grad_u.xy = Dual(sh.q[pt][1]); g.grad_u.xz = Dual(sh.q[pt][2]);
+  g.grad_u.yx = Dual(sh.q[pt][3]); g.grad_u.yy = Dual(sh.q[pt][4]); g.grad_u.yz = Dual(sh.q[pt][5]);
+  g.grad_u.zx = Dual(sh.q[pt][6]); g.grad_u.zy = Dual(sh.q[pt][7]); g.grad_u.zz = Dual(sh.q[pt][8]);
+  g.p = Dual(sh.q[pt][9]);
+  g.grad_p[0] = Dual(sh.q[pt][10]); g.grad_p[1] = Dual(sh.q[pt][11]); g.grad_p[2] = Dual(sh.q[pt][12]);
+  g.u[0] = Dual(sh.q[pt][13]); g.u[1] = Dual(sh.q[pt][14]); g.u[2] = Dual(sh.q[pt][15]);
+  if (prev) {
+    g.grad_u_prev.xx = Dual(sh.qprev[pt][0]); g.grad_u_prev.xy = Dual(sh.qprev[pt][1]); g.grad_u_prev.xz = Dual(sh.qprev[pt][2]);
+    g.grad_u_prev.yx = Dual(sh.qprev[pt][3]); g.grad_u_prev.yy = Dual(sh.qprev[pt][4]); g.grad_u_prev.yz = Dual(sh.qprev[pt][5]);
+    g.grad_u_prev.zx = Dual(sh.qprev[pt][6]); g.grad_u_prev.zy = Dual(sh.qprev[pt][7]); g.grad_u_prev.zz = Dual(sh.qprev[pt][8]);
+  } else {
+    g.grad_u_prev = scale(0., eye3<Dual>());
+  }
+}
+
+// seed point quantity c
+C8_HD void seed_q(PointState<Dual>& g, int c) {
+  g.grad_u.xx.d = (c == 0) ? 1. : 0.; g.grad_u.xy.d = (c == 1) ? 1. : 0.; g.grad_u.xz.d = (c == 2) ? 1. : 0.;
+  g.grad_u.yx.d = (c == 3) ? 1. : 0.; g.grad_u.yy.d = (c == 4) ? 1. : 0.; g.grad_u.yz.d = (c == 5) ? 1. : 0.;
+  g.grad_u.zx.d = (c == 6) ? 1. : 0.; g.grad_u.zy.d = (c == 7) ? 1. : 0.; g.grad_u.zz.d = (c == 8) ? 1. : 0.;
+  g.p.d = (c == 9) ? 1. : 0.;
+  g.grad_p[0].d = (c == 10) ? 1. : 0.; g.grad_p[1].d = (c == 11) ? 1. : 0.; g.grad_p[2].d = (c == 12) ? 1. : 0.;
+  g.u[0].d = (c == 13) ? 1. : 0.; g.u[1].d = (c == 14) ? 1. : 0.; g.u[2].d = (c == 15) ? 1. : 0.;
+}
+
+// interpolated value of point quantity c at point pt (global_residual.cpp:289-332)
+template <class E, class SH> C8_HD double interp_q(SH const& sh, int pt, int c, bool prev) {
+  double s = 0.;
+  if (c < 9) {
+    int const i = c / 3, l = c - 3 * i;
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += (prev ? sh.u_prev[n][i] : sh.u[n][i]) * sh.dN[pt][n][l];
+  } else if (c == 9) {
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += sh.p[n] * sh.N[pt][n];
+  } else if (c < 13) {
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += sh.p[n] * sh.dN[pt][n][c - 10];
+  } else {
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += sh.u[n][c - 13] * sh.N[pt][n];
+  }
+  return s;
+}
+
+// Gauss-Jordan with row pivoting inside lane groups of G lanes: lane cg (< NL) of a group owns
+// column cg of the group's matrix Mg (in shared memory); see gj_solve in c8_assemble.hpp.
+template <int NL, int G, class EX, class GetM, class GetB, class Active>
+C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
+  bool ok = true;
+  C8_UNROLL
+  for (int s = 0; s < NL; ++s) {
+    ex.each([&](int lane) {
+      if (!active(lane)) return;
+      int const cg = lane % G;
+      auto* M = getm(lane);  // double (*)[9]
+      double* b = getb(lane);
+      double col[NL];
+      C8_UNROLL
+      for (int r = 0; r < NL; ++r) col[r] = M[r][s];
+      int rstar = s;
+      double big = fabs(col[s]);
+      C8_UNROLL
+      for (int r = s + 1; r < NL; ++r) {
+        double const a = fabs(col[r]);
+        if (a > big) { big = a; rstar = r; }
+      }
+      if (!(big > 0.)) ok = false;
+      double const cs = col[s], bs = b[s];
+      double cpiv = cs, bpiv = bs;
+      static_for<NL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        bool const hit = (r > s) && (r == rstar);
+        cpiv = hit ? col[r] : cpiv;
+        bpiv = hit ? b[r] : bpiv;
+        col[r] = hit ? cs : col[r];
+        b[r] = hit ? bs : b[r];
+      });
+      double const inv = 1. / cpiv;
+      double const bsn = bpiv * inv;
+      b[s] = bsn;
+      C8_UNROLL
+      for (int r = 0; r < NL; ++r) if (r != s) b[r] -= col[r] * bsn;
+      if (cg > s && cg < NL) {
+        double const ms = M[s][cg], mr = M[rstar][cg];
+        M[rstar][cg] = ms;
+        double const msn = mr * inv;
+        M[s][cg] = msn;
+        C8_UNROLL
+        for (int r = 0; r < NL; ++r) if (r != s) M[r][cg] -= col[r] * msn;
+      }
+    });
+    ex.sync();
+  }
+  return ok;
+}
+
+template <class E, template <class> class ModelT, class EX>
+C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
+                                 ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
+  using Model = ModelT<Dual>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  static_assert(E::NDOF == 32 && E::NP0 == 8 && E::SAME_POINTS, "wave kernel needs a hex8-like element");
+  static_assert(NL <= 8, "at most 8 local unknowns per point");
+
+  // ---- load: lanes 0..31 = element DOF slots; shape tables: lane = point*8 + node ----------
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    r.failed = false;
+    r.R = 0.;
+    C8_UNROLL
+    for (int a = 0; a < 16; ++a) r.J[a] = 0.;
+    if (lane == 0) sh.failed = 0;
+    if (lane < E::NDOF) {
+      int i, n, eq;
+      slot_to_dof<E>(lane, i, n, eq);
+      int const node = mt.conn[e * E::NN + n];
+      if (i == 0) {
+        sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
+        sh.u[n][eq] = fa.u[(size_t)node * 3 + eq];
+        if (PREV) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * 3 + eq];
+      } else {
+        sh.p[n] = fa.p[node];
+        sh.node[n] = node;
+        int const a = mt.nodeptr[node];
+        sh.nptr[n] = a;
+        sh.deg[n] = mt.nodeptr[node + 1] - a;
+      }
+    }
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
+    if (lane == 0) sh.h = elem_size<E>(sh);
+  });
+  ex.sync();
+  // ---- interpolation: lane (pt, d) computes quantities 2d and 2d+1 (and grad_u_prev) --------------
+  ex.each([&](int lane) {
+    int const pt = lane >> 3, d = lane & 7;
+    sh.q[pt][2 * d] = interp_q<E>(sh, pt, 2 * d, false);
+    sh.q[pt][2 * d + 1] = interp_q<E>(sh, pt, 2 * d + 1, false);
+    if (PREV) {
+      sh.qprev[pt][d] = interp_q<E>(sh, pt, d, true);
+      if (d == 0) sh.qprev[pt][8] = interp_q<E>(sh, pt, 8, true);
+    }
+    if (d < NL) {
+      size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+      sh.xip[pt][d] = fa.xi_prev[q + d];
+      sh.xi[pt][d] = fa.xi[q + d];
+    }
+  });
+  ex.sync();
+
+  // ---- phase N: local Newton at all 8 points (small_J2.cpp:122-173) ---------------------------
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const pt = lane >> 3, d = lane & 7;
+    load_params(r.m, mt, e);
+    load_point(sh, pt, r.g, PREV);
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) {
+      r.m.xi_prev[j] = Dual(sh.xip[pt][j]);
+      r.m.xi[j] = Dual(sh.xi[pt][j], (j == d) ? 1. : 0.);
+      r.m.R[j] = Dual(0.);
+    }
+    r.m.initial_guess(r.g);
+    r.iter = 1;
+    r.R_norm_0 = 1.;
+    r.converged = !Model::HAS_LOCAL;
+  });
+  if (Model::HAS_LOCAL) {
+    auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
+    while (ex.any(running)) {
+      ex.each([&](int lane) {
+        auto& r = ex.lane(lane);
+        if (!running(lane)) return;
+        int const pt = lane >> 3, d = lane & 7;
+        r.m.evaluate(r.g, ms.abs_tol);
+        double nrm = 0.;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
+        double const R_norm = sqrt(nrm);
+        if (r.iter == 1) r.R_norm_0 = R_norm;
+        double const R_norm_rel = R_norm / r.R_norm_0;  // NaN on elastic points: the abs test decides
+        if ((R_norm_rel < ms.rel_tol) || (R_norm < ms.abs_tol)) r.converged = true;
+        if (d < NL) {
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.m.R[j].d;
+        }
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].v;
+      });
+      ex.sync();
+      if (!ex.any(running)) break;
+      bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                              [&](int lane) { return ex.lane(lane).b; }, running);
+      ex.each([&](int lane) {
+        auto& r = ex.lane(lane);
+        if (!running(lane)) return;
+        if (!ok) { r.failed = true; r.iter = ms.max_iters + 1; return; }
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.m.xi[j].v += r.b[j];
+        r.iter++;
+      });
+    }
+  }
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const pt = lane >> 3, d = lane & 7;
+    if ((r.iter > ms.max_iters) && !r.converged) r.failed = true;
+    if (d == 0) {  // local->scatter (local_residual.cpp:624-631)
+      size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) { fa.xi[q + j] = r.m.xi[j].v; sh.xi[pt][j] = r.m.xi[j].v; }
+      if (r.failed) sh.failed = 1;
+    }
+  });
+  ex.sync();
+
+  // ---- phases D and P, 4 points per pass -------------------------------------------------------------
+  for (int t = 0; t < 2; ++t) {
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
+      load_params(r.m, mt, e);
+      load_point(sh, pt, r.g, PREV);
+      seed_q(r.g, c);
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) {
+        r.m.xi_prev[j] = Dual(sh.xip[pt][j]);
+        r.m.xi[j] = Dual(sh.xi[pt][j]);
+        r.m.R[j] = Dual(0.);
+        r.b[j] = 0.;
+      }
+      if (Model::HAS_LOCAL) {  // dC/dq_c with xi unseeded (evaluations.cpp:105-109)
+        r.m.evaluate(r.g, ms.abs_tol);
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].d;
+      }
+    });
+    if (Model::HAS_LOCAL) {
+      ex.sync();
+      bool const ok = gj_solve_grouped<NL, 16>(ex, [&](int lane) { return sh.M[4 * t + (lane >> 4)]; },
+                                               [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+      if (!ok) ex.each([&](int lane) { if (lane == 0) sh.failed = 1; });
+    }
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];  // dxi/dq_c  (local->seed_wrt_x, chain rule through q)
+      MechFlux<Dual> f;
+      Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+      f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);  // ip set 1 has the same points and weights
+      double* Dc = &sh.D[ql][0][c];
+      constexpr int LD = WQ + 1;
+      Dc[0 * LD] = f.Gu.xx.d; Dc[1 * LD] = f.Gu.xy.d; Dc[2 * LD] = f.Gu.xz.d;
+      Dc[3 * LD] = f.Gu.yx.d; Dc[4 * LD] = f.Gu.yy.d; Dc[5 * LD] = f.Gu.yz.d;
+      Dc[6 * LD] = f.Gu.zx.d; Dc[7 * LD] = f.Gu.zy.d; Dc[8 * LD] = f.Gu.zz.d;
+      Dc[9 * LD] = f.Vp.d;
+      Dc[10 * LD] = f.Gp[0].d; Dc[11 * LD] = f.Gp[1].d; Dc[12 * LD] = f.Gp[2].d;
+      if (c == 0) {
+        double* Fp = sh.F[pt];
+        Fp[0] = f.Gu.xx.v; Fp[1] = f.Gu.xy.v; Fp[2] = f.Gu.xz.v;
+        Fp[3] = f.Gu.yx.v; Fp[4] = f.Gu.yy.v; Fp[5] = f.Gu.yz.v;
+        Fp[6] = f.Gu.zx.v; Fp[7] = f.Gu.zy.v; Fp[8] = f.Gu.zz.v;
+        Fp[9] = f.Vp.v;
+        Fp[10] = f.Gp[0].v; Fp[11] = f.Gp[1].v; Fp[12] = f.Gp[2].v;
+      }
+    });
+    ex.sync();
+    // phase P: lane = (half, column b); J[al] = entry (row of local node al/4.. , col b)
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const b = lane & 31, half = lane >> 5;
+      bool const bu = b < 3 * E::NN;
+      int const m = bu ? b / 3 : b - 3 * E::NN;
+      int const k = bu ? b - 3 * m : 0;
+      int const cg = bu ? 3 * k : 10;       // first gradient column of D that x_b drives
+      int const cv = bu ? 13 + k : 9;       // value column of D that x_b drives
+      C8_NOUNROLL
+      for (int ql = 0; ql < 4; ++ql) {
+        int const pt = 4 * t + ql;
+        double const w = sh.wdv[pt];
+        double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
+        double T[WF];
+        C8_UNROLL
+        for (int rr = 0; rr < WF; ++rr) {
+          double const* Dr = sh.D[ql][rr];
+          T[rr] = w * (Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cv] * bN);
+        }
+        C8_UNROLL
+        for (int nl = 0; nl < 4; ++nl) {
+          int const n = 4 * half + nl;
+          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+          r.J[4 * nl + 0] += a0 * T[0] + a1 * T[1] + a2 * T[2];
+          r.J[4 * nl + 1] += a0 * T[3] + a1 * T[4] + a2 * T[5];
+          r.J[4 * nl + 2] += a0 * T[6] + a1 * T[7] + a2 * T[8];
+          r.J[4 * nl + 3] += aN * T[9] + a0 * T[10] + a1 * T[11] + a2 * T[12];
+        }
+        if (half == 0) {  // residual entry b from the flux values
+          double const* Fp = sh.F[pt];
+          int const fr = bu ? 3 * k : 10;
+          double const rv = Fp[fr] * b0 + Fp[fr + 1] * b1 + Fp[fr + 2] * b2 + (bu ? 0. : Fp[9] * bN);
+          r.R += w * rv;
+        }
+      }
+    });
+    ex.sync();
+  }
+
+  // ---- scatter: lane (half, b) holds rows of nodes 4*half..4*half+3, column b -----------------------
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const b = lane & 31, half = lane >> 5;
+    int ib, nb, eqb;
+    slot_to_dof<E>(b, ib, nb, eqb);
+    int const neqb = ib == 0 ? 3 : 1;
+    uint8_t const* posb = mt.pos + ((size_t)e * E::NN + nb) * E::NN;  // pos[e][col node nb][row node]
+    C8_UNROLL
+    for (int nl = 0; nl < 4; ++nl) {
+      int const n = 4 * half + nl;
+      size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
+      C8_UNROLL
+      for (int i = 0; i < 3; ++i)  // u rows of node n: block (0, ib)
+        ex.add(sa.A[0][ib] + nptr * (3 * neqb) + (size_t)i * deg * neqb + pos * neqb + eqb, r.J[4 * nl + i], sa.atomic);
+      ex.add(sa.A[1][ib] + nptr * neqb + pos * neqb + eqb, r.J[4 * nl + 3], sa.atomic);  // p row: block (1, ib)
+    }
+    if (half == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, sa.atomic);
+    if (lane == 0 && sh.failed) ex.flag(sa.status);
+  });
+}
+
+}  // namespace c8

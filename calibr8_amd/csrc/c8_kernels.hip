@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "c8_assemble_adjoint.hpp"
+#include "c8_assemble_wave.hpp"
 #include "c8_kernels.hpp"
 
 namespace c8 {
@@ -62,6 +63,35 @@ static hipError_t launch_forward(LaunchArgs const& a) {
   int const grid = ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_forward_jacobian<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
+                     a.first, a.count, nblocks);
+  return hipGetLastError();
+}
+
+// K1, one wavefront per hex8 element (c8_assemble_wave.hpp); 4 elements per workgroup
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+                                                               int first, int count, int nblocks) {
+  constexpr int WPB = BLOCK / 64;
+  using Lane = WaveLane<ModelT>;
+  __shared__ WaveShared<E, ModelT<Dual>::NLOC> shs[WPB];
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int const gi = lb * WPB + wib;
+  if (gi >= count) return;
+  int const e = mt.order ? mt.order[first + gi] : first + gi;
+  Lane L;
+  GpuExec<Lane> ex(lane, L);
+  forward_jacobian_wave<E, ModelT>(ex, shs[wib], mt, ms, fa, sa, e);
+}
+
+template <class E, template <class> class ModelT>
+static hipError_t launch_forward_wave(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  int const nblocks = (a.count + WPB - 1) / WPB;
+  int const grid = ((nblocks + 7) / 8) * 8;
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_forward_jacobian_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
                      a.first, a.count, nblocks);
   return hipGetLastError();
 }
@@ -183,9 +213,17 @@ template <class E, template <class> class ModelT> static hipError_t launch_qoi(L
   return hipGetLastError();
 }
 
+template <class E, template <class> class ModelT> struct WaveKernel {
+  static LaunchFn get() { return nullptr; }
+};
+template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
+  static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
+};
+
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
   KernelSet ks;
   ks.forward_jacobian = &launch_forward<E, ModelT>;
+  ks.forward_jacobian_wave = WaveKernel<E, ModelT>::get();
   ks.residual = &launch_residual<E, ModelT>;
   ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;

@@ -22,7 +22,8 @@ struct LaunchArgs {
 typedef hipError_t (*LaunchFn)(LaunchArgs const&);
 
 struct KernelSet {
-  LaunchFn forward_jacobian;   // K1, colour-batched or atomic
+  LaunchFn forward_jacobian;   // K1, one lane group (NDOF lanes) per element
+  LaunchFn forward_jacobian_wave;  // K1, one wavefront per element (hex8 only, else null)
   LaunchFn residual;           // K2
   LaunchFn adjoint_jacobian;   // K3
   LaunchFn adjoint_local;      // K4 (per-point outputs only: one launch, no colouring)

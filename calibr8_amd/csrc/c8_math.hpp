@@ -24,8 +24,10 @@
 // arrays are only ever indexed by compile-time constants (no scratch memory)
 #if defined(__clang__)
 #define C8_UNROLL _Pragma("unroll")
+#define C8_NOUNROLL _Pragma("clang loop unroll(disable)")
 #else
 #define C8_UNROLL
+#define C8_NOUNROLL
 #endif
 
 namespace c8 {

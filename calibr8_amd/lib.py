@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, "libc8.so")
 C8_ELEM_TET4, C8_ELEM_HEX8 = 4, 8
 C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 C8_SCATTER_ATOMIC, C8_SCATTER_COLORED = 0, 1
+C8_KERNEL_AUTO, C8_KERNEL_SLOT, C8_KERNEL_WAVE = 0, 1, 2
 
 dp = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)
@@ -56,6 +57,7 @@ SYMBOLS = [
     ("c8_num_active_params", C.c_int, [C.c_void_p]),
     ("c8_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("c8_set_scatter_mode", C.c_int, [C.c_void_p, C.c_int]),
+    ("c8_set_kernel_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_status", C.c_int, [C.c_void_p]),
     ("c8_assemble_forward_jacobian", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),

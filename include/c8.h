@@ -38,6 +38,7 @@ typedef struct c8_ctx c8_ctx;
 enum { C8_ELEM_TET4 = 4, C8_ELEM_HEX8 = 8 };
 enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -3, C8_ERR_UNSUPPORTED = -4 };
 enum { C8_SCATTER_ATOMIC = 0, C8_SCATTER_COLORED = 1 };
+enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2 };
 
 /* One mesh part (what Disc holds after loadMdsMesh, disc.cpp:31-39): all nodes that touch a
  * local element, local (GHOST) numbering. */
@@ -111,6 +112,9 @@ int c8_set_active_params(c8_ctx* ctx, int elem_set, int n, const int32_t* param_
 int c8_num_active_params(const c8_ctx* ctx); /* total over element sets = length of grad */
 int c8_set_stream(c8_ctx* ctx, void* hip_stream);
 int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_COLORED (default) or C8_SCATTER_ATOMIC */
+/* Forward-assembly kernel: C8_KERNEL_SLOT = one lane group per element (any element type);
+ * C8_KERNEL_WAVE = one wavefront per element (hex8); C8_KERNEL_AUTO picks WAVE where available. */
+int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 /* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
  * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */
 int c8_set_async(c8_ctx* ctx, int async);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../calibr8_amd/csrc/c8_assemble_adjoint.hpp"
+#include "../../calibr8_amd/csrc/c8_assemble_wave.hpp"
 #include "../../calibr8_amd/csrc/c8_host.hpp"
 
 using namespace c8;
@@ -19,13 +20,13 @@ template <class Lane, int NDOF> struct CpuExec {
   Lane lanes[NDOF];
   template <class F> void each(F f) { for (int k = 0; k < NDOF; ++k) f(k); }
   Lane& lane(int k) { return lanes[k]; }
-  template <class F> bool any(F f) { return f(0); }
+  template <class F> bool any(F f) { bool a = false; for (int k = 0; k < NDOF; ++k) a = a || f(k); return a; }
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
   void flag(int* s) { *s = 1; }
 };
 
-enum { K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 struct Call {
   int what;
@@ -71,7 +72,24 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
   }
 }
 
+template <template <class> class ModelT> static void run_wave(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
+  auto* ex = new CpuExec<WaveLane<ModelT>, 64>();
+  for (int e = 0; e < c.nelems; ++e) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.sa, e);
+  delete ex;
+  delete sh;
+}
+
 template <class E> static int dispatch(std::string const& model, Call const& c) {
+  if (c.what == K_FORWARD_WAVE) {
+    if (E::TYPE != C8_HEX8) return -4;
+    if (model == "elastic") run_wave<Elastic>(c);
+    else if (model == "small_J2") run_wave<SmallJ2>(c);
+    else if (model == "hyper_J2") run_wave<HyperJ2>(c);
+    else return -2;
+    return 0;
+  }
   if (model == "elastic") run<E, Elastic>(c);
   else if (model == "small_J2") run<E, SmallJ2>(c);
   else if (model == "hyper_J2") run<E, HyperJ2>(c);

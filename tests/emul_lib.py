@@ -15,7 +15,7 @@ EMUL_DIR = os.path.join(HERE, "emul")
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
-K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI = 1, 2, 3, 4, 5, 6
+K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE = 1, 2, 3, 4, 5, 6, 7
 
 
 def lib():
@@ -44,6 +44,7 @@ class Emul:
         self.params = o.params
         self.active = np.zeros((o.nsets, 10), dtype=np.int32)
         self.set_active(0, [0])
+        self.wave = False  # True: K1 through the wave-per-element kernel (hex8 only)
 
     def new_state(self):
         return self.orc.new_state()
@@ -82,7 +83,8 @@ class Emul:
         return {6: ls.A[0][0], 7: ls.A[0][1], 8: ls.A[1][0], 9: ls.A[1][1], 10: ls.b[0], 11: ls.b[1]}
 
     def forward_jacobian(self, u, p, up, pp, xip, xi, ls):
-        return self._call(K_FORWARD, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
+        what = K_FORWARD_WAVE if self.wave else K_FORWARD
+        return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def global_residual(self, u, p, up, pp, xip, xi, ls):
         return self._call(K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})

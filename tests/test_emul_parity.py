@@ -34,3 +34,11 @@ def test_adjoint_chain(mesh, model, params, eps):
     # K3 -> K4 -> K5 on two consecutive load steps with non-trivial history vectors
     orc, dut, c = make_pair(factory, mesh, model, params)
     check_adjoint_chain(orc, dut, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_forward_jacobian_wave_kernel(model, params, eps):
+    # the one-wavefront-per-element hex8 kernel (c8_assemble_wave.hpp)
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.wave = True
+    check_forward(orc, dut, c, model, eps, TOL)

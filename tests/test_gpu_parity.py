@@ -30,11 +30,19 @@ def both(et, c, conn, model, params, scatter):
     return ol.Oracle(et, c, conn, model, params), GpuBackend(et, c, conn, model, params, scatter=scatter)
 
 
-def factory(scatter):
+def factory(scatter, kernel="auto"):
     def make(et, c, conn, model, params, **kw):
         from gpu_backend import GpuBackend
-        return GpuBackend(et, c, conn, model, params, scatter=scatter, **kw)
+        return GpuBackend(et, c, conn, model, params, scatter=scatter, kernel=kernel, **kw)
     return make
+
+
+@pytest.mark.parametrize("scatter", ["colored", "atomic"])
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_forward_jacobian_slot_kernel_hex8(model, params, eps, scatter):
+    # hex8 defaults to the wave-per-element kernel; the slot-per-lane kernel stays covered here
+    orc, gpu, c = make_pair(factory(scatter, "slot"), "hex8", model, params)
+    check_forward(orc, gpu, c, model, eps, TOL)
 
 
 @pytest.mark.parametrize("scatter", ["colored", "atomic"])
