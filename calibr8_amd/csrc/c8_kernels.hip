@@ -69,7 +69,7 @@ static hipError_t launch_forward(LaunchArgs const& a) {
 
 // K1, one wavefront per hex8 element (c8_assemble_wave.hpp); 4 elements per workgroup
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK) k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+__global__ void __launch_bounds__(BLOCK, 2) k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
                                                                int first, int count, int nblocks) {
   constexpr int WPB = BLOCK / 64;
   using Lane = WaveLane<ModelT>;
