@@ -281,6 +281,42 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
     }
   });
   ex.sync();
+  // ---- (dC/dxi)^-1 once per point, in the 8-lane layout: lane d solves for unit vector e_d.  Both passes
+  //      of phase D then apply it as a matrix-vector product instead of two more eliminations.  When every
+  //      point of the element took the elastic branch dC/dxi is exactly I (R = xi - xi_trial) and the
+  //      elimination is skipped: solving I x = b returns b unchanged, so the result is bitwise the same.
+  bool need_inverse = false;
+  if (Model::HAS_LOCAL) {
+    need_inverse = ex.any_wave([&](int lane) {
+      int const pt = lane >> 3, d = lane & 7;
+      bool notI = false;
+      if (d < NL) {
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) notI = notI || (sh.M[pt][j][d] != ((j == d) ? 1. : 0.));
+      }
+      return notI;
+    });
+    if (need_inverse) {
+      ex.each([&](int lane) {
+        auto& r = ex.lane(lane);
+        int const d = lane & 7;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.b[j] = (j == d) ? 1. : 0.;
+      });
+      bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                              [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+      ex.each([&](int lane) {
+        auto& r = ex.lane(lane);
+        int const pt = lane >> 3, d = lane & 7;
+        if (d < NL) {
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.b[j];
+        }
+        if (!ok && lane == 0) sh.failed = 1;
+      });
+      ex.sync();
+    }
+  }
 
   // ---- phases D and P, 4 points per pass -------------------------------------------------------------
   for (int t = 0; t < 2; ++t) {
@@ -302,18 +338,19 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
         C8_UNROLL
         for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].d;
       }
-    });
-    if (Model::HAS_LOCAL) {
-      ex.sync();
-      bool const ok = gj_solve_grouped<NL, 16>(ex, [&](int lane) { return sh.M[4 * t + (lane >> 4)]; },
-                                               [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
-      if (!ok) ex.each([&](int lane) { if (lane == 0) sh.failed = 1; });
-    }
-    ex.each([&](int lane) {
-      auto& r = ex.lane(lane);
-      int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
-      C8_UNROLL
-      for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];  // dxi/dq_c  (local->seed_wrt_x, chain rule through q)
+      // dxi/dq_c = -(dC/dxi)^-1 dC/dq_c  (evaluations.cpp:112; local->seed_wrt_x, chain rule through q)
+      if (Model::HAS_LOCAL && need_inverse) {
+        C8_UNROLL
+        for (int i = 0; i < NL; ++i) {
+          double sacc = 0.;
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) sacc += sh.M[pt][i][j] * r.b[j];
+          r.m.xi[i].d = sacc;
+        }
+      } else {
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];
+      }
       MechFlux<Dual> f;
       Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
       f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);  // ip set 1 has the same points and weights
@@ -343,6 +380,7 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
       int const k = bu ? b - 3 * m : 0;
       int const cg = bu ? 3 * k : 10;       // first gradient column of D that x_b drives
       int const cv = bu ? 13 + k : 9;       // value column of D that x_b drives
+      bool const has_cv = Mechanics::USES_U || !bu;  // the weak form does not read u itself
       C8_NOUNROLL
       for (int ql = 0; ql < 4; ++ql) {
         int const pt = 4 * t + ql;
@@ -352,7 +390,9 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
         C8_UNROLL
         for (int rr = 0; rr < WF; ++rr) {
           double const* Dr = sh.D[ql][rr];
-          T[rr] = w * (Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cv] * bN);
+          double tt = Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2;
+          if (has_cv) tt += Dr[cv] * bN;
+          T[rr] = w * tt;
         }
         C8_UNROLL
         for (int nl = 0; nl < 4; ++nl) {

@@ -19,6 +19,7 @@ template <class Lane> struct GpuExec {
   template <class F> __device__ __forceinline__ void each(F f) { f(k); }
   __device__ __forceinline__ Lane& lane(int) { return L; }
   template <class F> __device__ __forceinline__ bool any(F f) { return f(k); }
+  template <class F> __device__ __forceinline__ bool any_wave(F f) { return __any(f(k)) != 0; }
   __device__ __forceinline__ void sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();

@@ -227,6 +227,7 @@ template <class T> struct MechFlux {
 };
 
 struct Mechanics {
+  static constexpr bool USES_U = false;  // the integrand reads grad u, p, grad p but not u (mechanics.cpp:116-227)
   template <class T, class Local>
   C8_HD static void flux_coupled(Local const& local, PointState<T> const& g, double h, double stab_mult, MechFlux<T>& f) {
     Tens3<T> stress = local.cauchy(g);

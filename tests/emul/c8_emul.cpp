@@ -21,6 +21,7 @@ template <class Lane, int NDOF> struct CpuExec {
   template <class F> void each(F f) { for (int k = 0; k < NDOF; ++k) f(k); }
   Lane& lane(int k) { return lanes[k]; }
   template <class F> bool any(F f) { bool a = false; for (int k = 0; k < NDOF; ++k) a = a || f(k); return a; }
+  template <class F> bool any_wave(F f) { return any(f); }
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
   void flag(int* s) { *s = 1; }
