@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--edge", dest="n", type=int, default=100, help="brick edge (elements) per GPU")
-    ap.add_argument("--scatter", default="colored", choices=["colored", "atomic"])
+    ap.add_argument("--scatter", default="atomic", choices=["colored", "atomic"])
     ap.add_argument("--cpu-sample", type=int, default=24, help="edge of the CPU-baseline sample brick")
     ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
     ap.add_argument("--no-cpu", action="store_true")
