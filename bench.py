@@ -34,6 +34,23 @@ def algorithmic_bytes(nelems, nnodes, nnz_total, nen=8, nqp=8, nloc=7, ndofn=4):
     return nelems * (4 * nen + 8 * nqp * nloc * 2) + nnodes * 8 * (3 + 2 * ndofn + ndofn) + 8 * nnz_total
 
 
+def measured_traffic(edge, scatter, kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*traffic*.json, collected as MI355X_MICROARCH.md prescribes); None if there is no
+    profile for this configuration.  PMC counters cannot be read from inside the timed process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        c = d.get("config", {})
+        if c.get("edge") == edge and c.get("scatter") == scatter and c.get("kernel") == kernel:
+            best = d.get("traffic_bytes_per_launch")
+    return best
+
+
 def cpu_baseline(n, nthreads):
     """Oracle (CPU restatement of the reference algorithm) timed on an n^3 sample of the same workload."""
     import oracle_lib as ol
@@ -167,7 +184,8 @@ def main():
         balg = algorithmic_bytes(asm.nelems, asm.nnodes, nnz_total)
         achieved = balg / (kernel_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": measured_traffic(n, args.scatter, "slot" if args.kernel == "slot" else "wave"),
                            "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
                            "kernel": ("k_forward_jacobian" if args.kernel == "slot" else "k_forward_jacobian_wave") +
                                      "<hex8,small_J2> (%d launches per step)"
