@@ -305,7 +305,9 @@ int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
   AdjointArgs aa{g, const_cast<double*>(f), nullptr, nullptr, nullptr, nullptr, c->d_active};
-  return run(c, c->ks.adjoint_jacobian, field_args(st), aa, sa, true, "c8_assemble_adjoint_jacobian");
+  LaunchFn fn = c->ks.adjoint_jacobian;
+  if (c->ks.adjoint_jacobian_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.adjoint_jacobian_wave;
+  return run(c, fn, field_args(st), aa, sa, true, "c8_assemble_adjoint_jacobian");
 }
 
 int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[2], double* phi, double* g, double* f) {

@@ -43,6 +43,8 @@ template <class E, int NL> struct WaveShared {
   double xip[E::NP0][NLP];          // previous local state
   double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
   double F[E::NP0][WQ];             // flux values
+  double gh[E::NP0][NLP];           // adjoint: local history g at each point
+  double rq[4][WQ + 1];             // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
   double h;
   int32_t node[E::NN];
   int32_t nptr[E::NN], deg[E::NN];
@@ -159,9 +161,13 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
   return ok;
 }
 
-template <class E, template <class> class ModelT, class EX>
-C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
-                                 ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
+// ADJOINT = false: eval_forward_jacobian (evaluations.cpp:12-154)
+// ADJOINT = true : eval_adjoint_jacobian (evaluations.cpp:349-526): no local solve (stored xi), the element
+//                  matrix is scattered transposed, and the right-hand side is -dJ/dx + f + (dxi/dx)^T g with
+//                  g -= dJ/dxi updated in place; every x-derivative goes through the point quantities q.
+template <class E, template <class> class ModelT, class QoI, bool ADJOINT, class EX>
+C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, ModelSettings const& ms,
+                         FieldArgs const& fa, AdjointArgs const& aa, SystemArgs const& sa, int e) {
   using Model = ModelT<Dual>;
   constexpr int NL = Model::NLOC;
   constexpr bool PREV = Model::FINITE_DEF;
@@ -228,12 +234,29 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
       r.m.xi[j] = Dual(sh.xi[pt][j], (j == d) ? 1. : 0.);
       r.m.R[j] = Dual(0.);
     }
-    r.m.initial_guess(r.g);
+    if (!ADJOINT) r.m.initial_guess(r.g);
     r.iter = 1;
     r.R_norm_0 = 1.;
     r.converged = !Model::HAS_LOCAL;
+    if (ADJOINT) {  // evaluate at the stored state with xi seeded -> dC/dxi; dJ/dxi; g -= dJ/dxi  (:442-446, :474-481)
+      r.converged = true;
+      if (Model::HAS_LOCAL) {
+        r.m.evaluate(r.g, ms.abs_tol);
+        if (d < NL) {
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.m.R[j].d;
+        }
+      }
+      double const dJ_dxi = QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;
+      if (d < NL) {
+        size_t const qg = ((size_t)e * E::NP0 + pt) * NL + d;
+        double const gk = aa.g[qg] - dJ_dxi;
+        aa.g[qg] = gk;
+        sh.gh[pt][d] = gk;
+      }
+    }
   });
-  if (Model::HAS_LOCAL) {
+  if (Model::HAS_LOCAL && !ADJOINT) {
     auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
     while (ex.any(running)) {
       ex.each([&](int lane) {
@@ -273,7 +296,7 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
     auto& r = ex.lane(lane);
     int const pt = lane >> 3, d = lane & 7;
     if ((r.iter > ms.max_iters) && !r.converged) r.failed = true;
-    if (d == 0) {  // local->scatter (local_residual.cpp:624-631)
+    if (d == 0 && !ADJOINT) {  // local->scatter (local_residual.cpp:624-631)
       size_t const q = ((size_t)e * E::NP0 + pt) * NL;
       C8_UNROLL
       for (int j = 0; j < NL; ++j) { fa.xi[q + j] = r.m.xi[j].v; sh.xi[pt][j] = r.m.xi[j].v; }
@@ -338,6 +361,8 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
         C8_UNROLL
         for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].d;
       }
+      double dJ_dq = 0.;
+      if (ADJOINT) dJ_dq = QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;  // x seeded, xi plain (:469-471)
       // dxi/dq_c = -(dC/dxi)^-1 dC/dq_c  (evaluations.cpp:112; local->seed_wrt_x, chain rule through q)
       if (Model::HAS_LOCAL && need_inverse) {
         C8_UNROLL
@@ -350,6 +375,12 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
       } else {
         C8_UNROLL
         for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];
+      }
+      if (ADJOINT) {
+        double v = -dJ_dq;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) v += r.m.xi[j].d * sh.gh[pt][j];
+        sh.rq[ql][c] = v;
       }
       MechFlux<Dual> f;
       Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
@@ -386,35 +417,62 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
         int const pt = 4 * t + ql;
         double const w = sh.wdv[pt];
         double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
-        double T[WF];
-        C8_UNROLL
-        for (int rr = 0; rr < WF; ++rr) {
-          double const* Dr = sh.D[ql][rr];
-          double tt = Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2;
-          if (has_cv) tt += Dr[cv] * bN;
-          T[rr] = w * tt;
+        if (!ADJOINT) {
+          double T[WF];  // T[r] = w * sum_c D[r][c] dq_c/dx_b
+          C8_UNROLL
+          for (int rr = 0; rr < WF; ++rr) {
+            double const* Dr = sh.D[ql][rr];
+            double tt = Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2;
+            if (has_cv) tt += Dr[cv] * bN;
+            T[rr] = w * tt;
+          }
+          C8_UNROLL
+          for (int nl = 0; nl < 4; ++nl) {
+            int const n = 4 * half + nl;
+            double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+            r.J[4 * nl + 0] += a0 * T[0] + a1 * T[1] + a2 * T[2];
+            r.J[4 * nl + 1] += a0 * T[3] + a1 * T[4] + a2 * T[5];
+            r.J[4 * nl + 2] += a0 * T[6] + a1 * T[7] + a2 * T[8];
+            r.J[4 * nl + 3] += aN * T[9] + a0 * T[10] + a1 * T[11] + a2 * T[12];
+          }
+        } else {
+          // transposed element matrix computed directly, so that the lanes of one scatter instruction
+          // still share a CSR row: lane = element ROW a (flux side), loop over element COLUMNS (q side)
+          double U[WQ];  // U[c] = w * sum_r dR_a/dflux_r D[r][c]
+          C8_UNROLL
+          for (int c = 0; c < WQ; ++c) {
+            double tt = sh.D[ql][cg][c] * b0 + sh.D[ql][cg + 1][c] * b1 + sh.D[ql][cg + 2][c] * b2;
+            if (!bu) tt += sh.D[ql][9][c] * bN;
+            U[c] = w * tt;
+          }
+          C8_UNROLL
+          for (int nl = 0; nl < 4; ++nl) {
+            int const n = 4 * half + nl;
+            double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+            r.J[4 * nl + 0] += a0 * U[0] + a1 * U[1] + a2 * U[2] + (Mechanics::USES_U ? aN * U[13] : 0.);
+            r.J[4 * nl + 1] += a0 * U[3] + a1 * U[4] + a2 * U[5] + (Mechanics::USES_U ? aN * U[14] : 0.);
+            r.J[4 * nl + 2] += a0 * U[6] + a1 * U[7] + a2 * U[8] + (Mechanics::USES_U ? aN * U[15] : 0.);
+            r.J[4 * nl + 3] += aN * U[9] + a0 * U[10] + a1 * U[11] + a2 * U[12];
+          }
         }
-        C8_UNROLL
-        for (int nl = 0; nl < 4; ++nl) {
-          int const n = 4 * half + nl;
-          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
-          r.J[4 * nl + 0] += a0 * T[0] + a1 * T[1] + a2 * T[2];
-          r.J[4 * nl + 1] += a0 * T[3] + a1 * T[4] + a2 * T[5];
-          r.J[4 * nl + 2] += a0 * T[6] + a1 * T[7] + a2 * T[8];
-          r.J[4 * nl + 3] += aN * T[9] + a0 * T[10] + a1 * T[11] + a2 * T[12];
-        }
-        if (half == 0) {  // residual entry b from the flux values
+        if (half == 0 && !ADJOINT) {  // residual entry b from the flux values
           double const* Fp = sh.F[pt];
           int const fr = bu ? 3 * k : 10;
           double const rv = Fp[fr] * b0 + Fp[fr + 1] * b1 + Fp[fr + 2] * b2 + (bu ? 0. : Fp[9] * bN);
           r.R += w * rv;
+        }
+        if (half == 0 && ADJOINT) {  // rhs_b = sum_c [-dJ/dq_c + (dxi/dq_c).g] dq_c/dx_b + f_b  (:486-487)
+          double const* rq = sh.rq[ql];
+          r.R += rq[cg] * b0 + rq[cg + 1] * b1 + rq[cg + 2] * b2 + rq[cv] * bN +
+                 aa.f[((size_t)e * E::NP0 + pt) * E::NDOF + b];
         }
       }
     });
     ex.sync();
   }
 
-  // ---- scatter: lane (half, b) holds rows of nodes 4*half..4*half+3, column b -----------------------
+  // ---- scatter: lane (half, b) holds the entries (rows of nodes 4*half..4*half+3, column b); the adjoint
+  //      assembly stores them transposed (evaluations.cpp:463-465) ------------------------------------------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
     int const b = lane & 31, half = lane >> 5;
@@ -425,6 +483,8 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
     C8_UNROLL
     for (int nl = 0; nl < 4; ++nl) {
       int const n = 4 * half + nl;
+      // forward: J[(n,i)][b]; adjoint: the lane already holds the transposed entries J[b][(n,i)], so in
+      // both cases this is assembled entry (row (n,i), column b) and the lanes of one instruction share rows
       size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
       C8_UNROLL
       for (int i = 0; i < 3; ++i)  // u rows of node n: block (0, ib)
@@ -434,6 +494,19 @@ C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
     if (half == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, sa.atomic);
     if (lane == 0 && sh.failed) ex.flag(sa.status);
   });
+}
+
+template <class E, template <class> class ModelT, class EX>
+C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
+                                 ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
+  jacobian_wave<E, ModelT, AvgDisp, false>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
+}
+
+template <class E, template <class> class ModelT, class QoI, class EX>
+C8_HD void adjoint_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
+                                 ModelSettings const& ms, FieldArgs const& fa, AdjointArgs const& aa,
+                                 SystemArgs const& sa, int e) {
+  jacobian_wave<E, ModelT, QoI, true>(ex, sh, mt, ms, fa, aa, sa, e);
 }
 
 }  // namespace c8

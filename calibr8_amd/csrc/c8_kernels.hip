@@ -97,6 +97,34 @@ static hipError_t launch_forward_wave(LaunchArgs const& a) {
   return hipGetLastError();
 }
 
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK, 2) k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+                                                                  SystemArgs sa, int first, int count, int nblocks) {
+  constexpr int WPB = BLOCK / 64;
+  using Lane = WaveLane<ModelT>;
+  __shared__ WaveShared<E, ModelT<Dual>::NLOC> shs[WPB];
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int const gi = lb * WPB + wib;
+  if (gi >= count) return;
+  int const e = mt.order ? mt.order[first + gi] : first + gi;
+  Lane L;
+  GpuExec<Lane> ex(lane, L);
+  adjoint_jacobian_wave<E, ModelT, AvgDisp>(ex, shs[wib], mt, ms, fa, aa, sa, e);
+}
+
+template <class E, template <class> class ModelT>
+static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  int const nblocks = (a.count + WPB - 1) / WPB;
+  int const grid = ((nblocks + 7) / 8) * 8;
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_adjoint_jacobian_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa,
+                     a.sa, a.first, a.count, nblocks);
+  return hipGetLastError();
+}
+
 // group index -> element for the colour-batched / atomic element-parallel kernels
 #define C8_GROUP_PROLOGUE(E)                                                  \
   constexpr int GPB = BLOCK / E::NDOF;                                        \
@@ -216,15 +244,18 @@ template <class E, template <class> class ModelT> static hipError_t launch_qoi(L
 
 template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get() { return nullptr; }
+  static LaunchFn get_adjoint() { return nullptr; }
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_adjoint() { return &launch_adjoint_jacobian_wave<Elem<C8_HEX8>, ModelT>; }
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
   KernelSet ks;
   ks.forward_jacobian = &launch_forward<E, ModelT>;
   ks.forward_jacobian_wave = WaveKernel<E, ModelT>::get();
+  ks.adjoint_jacobian_wave = WaveKernel<E, ModelT>::get_adjoint();
   ks.residual = &launch_residual<E, ModelT>;
   ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;

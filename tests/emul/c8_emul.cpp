@@ -27,7 +27,7 @@ template <class Lane, int NDOF> struct CpuExec {
   void flag(int* s) { *s = 1; }
 };
 
-enum { K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 struct Call {
   int what;
@@ -77,13 +77,16 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
   auto* ex = new CpuExec<WaveLane<ModelT>, 64>();
-  for (int e = 0; e < c.nelems; ++e) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.sa, e);
+  for (int e = 0; e < c.nelems; ++e) {
+    if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.sa, e);
+    else adjoint_jacobian_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+  }
   delete ex;
   delete sh;
 }
 
 template <class E> static int dispatch(std::string const& model, Call const& c) {
-  if (c.what == K_FORWARD_WAVE) {
+  if (c.what == K_FORWARD_WAVE || c.what == K_ADJ_JAC_WAVE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "elastic") run_wave<Elastic>(c);
     else if (model == "small_J2") run_wave<SmallJ2>(c);

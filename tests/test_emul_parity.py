@@ -42,3 +42,10 @@ def test_forward_jacobian_wave_kernel(model, params, eps):
     orc, dut, c = make_pair(factory, "hex8", model, params)
     dut.wave = True
     check_forward(orc, dut, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_adjoint_chain_wave_kernel(model, params, eps):
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.wave = True
+    check_adjoint_chain(orc, dut, c, model, eps, TOL)

@@ -37,6 +37,12 @@ def factory(scatter, kernel="auto"):
     return make
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_adjoint_chain_slot_kernel_hex8(model, params, eps):
+    orc, gpu, c = make_pair(factory("colored", "slot"), "hex8", model, params)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+
+
 @pytest.mark.parametrize("scatter", ["colored", "atomic"])
 @pytest.mark.parametrize("model,params,eps", CASES)
 def test_forward_jacobian_slot_kernel_hex8(model, params, eps, scatter):

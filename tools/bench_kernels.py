@@ -1,0 +1,72 @@
+"""Times every entry point of the C ABI on the bench workload (100^3 hex8 brick, small_J2).
+Not the contract bench (that is ../bench.py): a per-kernel table for DESIGN.md / profiles."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--edge", type=int, default=100)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--scatter", default="atomic")
+    args = ap.parse_args()
+    import torch
+    from calibr8_amd import Assembler, brick_mesh
+    from meshes import prescribed_fields
+    n = args.edge
+    coords, conn = brick_mesh(n, n, n)
+    asm = Assembler(8, coords, conn, "small_J2", J2, scatter=args.scatter)
+    asm.set_active(0, [0, 1, 2, 3])
+    asm.set_async(True)
+    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
+    xi0, xi = asm.new_state(), asm.new_state()
+    ls = asm.new_linsys()
+    g = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=asm.device)
+    f = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=asm.device)
+    phi = torch.zeros_like(g)
+    z_u, z_p = torch.randn_like(u) * 1e-3, torch.randn_like(p) * 1e-3
+    grad = torch.zeros(4, dtype=torch.float64, device=asm.device)
+    J = torch.zeros(1, dtype=torch.float64, device=asm.device)
+
+    def timeit(fn):
+        fn()
+        assert asm.status() == 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(args.reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        assert asm.status() == 0
+        return a.elapsed_time(b) / args.reps
+
+    res = {}
+    for k in ("wave", "slot"):
+        asm.set_kernel(k)
+        res["forward_jacobian_" + k] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))
+    for k in ("wave", "slot"):
+        asm.set_kernel(k)
+        res["adjoint_jacobian_" + k] = timeit(lambda: asm.adjoint_jacobian(u, p, u0, p0, xi0, xi, g, f, ls))
+    asm.set_kernel("auto")
+    res["residual"] = timeit(lambda: asm.global_residual(u, p, u0, p0, xi0, xi, ls))
+    res["solve_adjoint_local"] = timeit(lambda: asm.solve_adjoint_local(u, p, u0, p0, xi0, xi, z_u, z_p, phi, g, f))
+    res["param_gradient"] = timeit(lambda: asm.qoi_gradient(u, p, u0, p0, xi0, xi, z_u, z_p, phi, grad))
+    res["eval_qoi"] = timeit(lambda: asm.eval_qoi(u, p, J))
+    out = {"elements": asm.nelems, "scatter": args.scatter,
+           "ms": res, "Melem_per_s": {k: asm.nelems / v / 1e3 for k, v in res.items()}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
