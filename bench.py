@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--edge", dest="n", type=int, default=100, help="brick edge (elements) per GPU")
     ap.add_argument("--scatter", default="atomic", choices=["colored", "atomic"])
-    ap.add_argument("--cpu-sample", type=int, default=24, help="edge of the CPU-baseline sample brick")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="edge of the CPU-baseline sample brick")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -191,11 +192,18 @@ def main():
                                      "<hex8,small_J2> (%d launches per step)"
                                      % (asm.ncolors if args.scatter == "colored" else 1)}
         if not args.no_cpu and world == 1:
-            nthreads = 1
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            nthreads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(16, avail))
+            v1 = cpu_baseline(12, 1)[0]  # single-core rate on a small sample, for reference
             v, orc, (cu, cp, cz, czp), ls_o, xi_o = cpu_baseline(args.cpu_sample, nthreads)
             out["cpu_baseline"] = {"value": v, "unit": "elements/s", "cores": nthreads, "kind": "port",
-                                   "sample": "%d^3 hex8 brick (%d elements) of the same workload, oracle/libc8oracle.so, "
-                                             "g++ -O2" % (args.cpu_sample, args.cpu_sample ** 3)}
+                                   "sample": "%d^3 hex8 brick (%d elements) of the same workload; oracle/libc8oracle.so "
+                                             "(CPU restatement of the reference algorithm, g++ -O2), %d threads, one "
+                                             "element slice per thread and colour" % (args.cpu_sample, args.cpu_sample ** 3, nthreads),
+                                   "value_1core": v1}
             # parity gate on the sample: the same sub-problem through the HIP path
             from gpu_backend import GpuBackend
             from parity import compare_systems, rel_vec

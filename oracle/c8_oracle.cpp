@@ -1038,6 +1038,8 @@ struct Ctx {
   std::vector<int> conn;
   std::vector<int> extra_pairs;  // extra (row node, col node) graph entries (multi-part union pattern)
   std::vector<std::vector<int>> set_elems;
+  std::vector<int> elem_set_of;
+  std::vector<std::vector<int>> colors;  // element colouring for the multi-thread baseline only
   // node graph (sorted neighbour lists) and the 2x2 dof-level CSR blocks
   std::vector<int64_t> nodeptr;
   std::vector<int> nodeadj;
@@ -1164,7 +1166,7 @@ static void scatter_rhs(Ctx const& c, Global<T> const& g, int e, double const* r
 // the set loop lets the multi-thread baseline give each thread a partition.
 // ---------------------------------------------------------------------------
 static int forward_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, LinSys& ls, int set_filter,
-                            int e_begin, int e_end) {
+                            int e_begin, int e_end, std::vector<int> const* elist = nullptr) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
   global.before_elems(c.kit.nn);
@@ -1174,8 +1176,9 @@ static int forward_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, LinSys& 
   for (int es = 0; es < c.nsets; ++es) {
     if (set_filter >= 0 && es != set_filter) continue;
     local.before_elems(&c.params[(size_t)es * c.nparams], c.nparams);
-    for (int e : c.set_elems[es]) {
+    for (int e : (elist ? *elist : c.set_elems[es])) {
       if (e < e_begin || e >= e_end) continue;
+      if (elist && c.nsets > 1 && c.elem_set_of[e] != es) continue;
       double X[8][3], N[8], dN[8][3];
       elem_coords(c, e, X);
       global.h = elem_size(c, X);
@@ -1524,7 +1527,11 @@ void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, in
   c->coords.assign(coords, coords + (size_t)nnodes * 3);
   c->conn.assign(conn, conn + (size_t)nelems * c->kit.nn);
   c->set_elems.resize(nsets);
-  for (int e = 0; e < nelems; ++e) c->set_elems[elem_set ? elem_set[e] : 0].push_back(e);
+  c->elem_set_of.resize(nelems);
+  for (int e = 0; e < nelems; ++e) {
+    c->elem_set_of[e] = elem_set ? elem_set[e] : 0;
+    c->set_elems[c->elem_set_of[e]].push_back(e);
+  }
   c->local_type = local_type;
   c->stab_mult = stab_mult;
   c->max_iters = max_iters;
@@ -1577,49 +1584,54 @@ int c8o_forward_jacobian(void* h, double const* u, double const* p, double const
   return forward_jacobian(*c, *c->local_f, f, ls, -1, 0, c->nelems);
 }
 
-// Multi-thread CPU baseline: one contiguous element partition per thread with
-// private accumulators and an ordered final sum -- the analogue of one
-// single-threaded MPI rank per core, which is how the reference scales.
+// Multi-thread CPU baseline: the analogue of one single-threaded MPI rank per core, which is how the
+// reference scales (Kokkos Serial).  Elements are greedily coloured (same-colour elements share no node);
+// within a colour every thread takes a contiguous slice and adds straight into the shared A and b, so no
+// private copies of the matrix are needed.  The summation order differs from the serial path (colour by
+// colour instead of element order); this entry point is used for timing only, never for parity.
+static void color_elements(Ctx& c) {
+  if (!c.colors.empty()) return;
+  int const nn = c.kit.nn;
+  std::vector<uint64_t> used(c.nnodes, 0);
+  for (int e = 0; e < c.nelems; ++e) {
+    uint64_t mask = 0;
+    for (int a = 0; a < nn; ++a) mask |= used[c.conn[e * nn + a]];
+    int col = 0;
+    while ((mask >> col) & 1) ++col;
+    for (int a = 0; a < nn; ++a) used[c.conn[e * nn + a]] |= (uint64_t)1 << col;
+    if ((int)c.colors.size() <= col) c.colors.resize(col + 1);
+    c.colors[col].push_back(e);
+  }
+}
+
 int c8o_forward_jacobian_mt(void* h, int nthreads, double const* u, double const* p, double const* u_prev,
                             double const* p_prev, double const* xi_prev, double* xi, double* A00, double* A01,
                             double* A10, double* A11, double* b0, double* b1) {
   Ctx* c = (Ctx*)h;
   if (nthreads <= 1) return c8o_forward_jacobian(h, u, p, u_prev, p_prev, xi_prev, xi, A00, A01, A10, A11, b0, b1);
-  size_t const nnz[2][2] = {{c->colidx[0][0].size(), c->colidx[0][1].size()},
-                            {c->colidx[1][0].size(), c->colidx[1][1].size()}};
-  size_t const nb[2] = {(size_t)c->nnodes * 3, (size_t)c->nnodes};
-  std::vector<std::vector<double>> priv(nthreads);
-  std::vector<int> status(nthreads, 0);
-  std::vector<std::thread> th;
-  size_t const total = nnz[0][0] + nnz[0][1] + nnz[1][0] + nnz[1][1] + nb[0] + nb[1];
+  color_elements(*c);
+  std::vector<Local<Fad>*> locals(nthreads);
   for (int t = 0; t < nthreads; ++t) {
-    priv[t].assign(total, 0.);
-    th.emplace_back([&, t]() {
-      double* q = priv[t].data();
-      LinSys ls;
-      ls.A[0][0] = q; q += nnz[0][0];
-      ls.A[0][1] = q; q += nnz[0][1];
-      ls.A[1][0] = q; q += nnz[1][0];
-      ls.A[1][1] = q; q += nnz[1][1];
-      ls.b[0] = q; q += nb[0];
-      ls.b[1] = q;
-      Local<Fad>* local = make_local<Fad>(c->local_type);
-      local->max_iters = c->max_iters; local->abs_tol = c->abs_tol; local->rel_tol = c->rel_tol;
-      Fields f{u, p, u_prev, p_prev, xi_prev, xi};
-      int const e0 = (int)((int64_t)c->nelems * t / nthreads), e1 = (int)((int64_t)c->nelems * (t + 1) / nthreads);
-      status[t] = forward_jacobian(*c, *local, f, ls, -1, e0, e1);
-      delete local;
-    });
+    locals[t] = make_local<Fad>(c->local_type);
+    locals[t]->max_iters = c->max_iters; locals[t]->abs_tol = c->abs_tol; locals[t]->rel_tol = c->rel_tol;
   }
-  for (auto& t : th) t.join();
-  double* out[6] = {A00, A01, A10, A11, b0, b1};
-  size_t const len[6] = {nnz[0][0], nnz[0][1], nnz[1][0], nnz[1][1], nb[0], nb[1]};
   int rc = 0;
-  for (int t = 0; t < nthreads; ++t) {
-    if (status[t] != 0) rc = -1;
-    double const* q = priv[t].data();
-    for (int k = 0; k < 6; ++k) { for (size_t i = 0; i < len[k]; ++i) out[k][i] += q[i]; q += len[k]; }
+  for (auto const& col : c->colors) {
+    std::vector<int> status(nthreads, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) {
+      th.emplace_back([&, t]() {
+        size_t const n = col.size();
+        std::vector<int> mine(col.begin() + n * t / nthreads, col.begin() + n * (t + 1) / nthreads);
+        Fields f{u, p, u_prev, p_prev, xi_prev, xi};
+        LinSys ls{{{A00, A01}, {A10, A11}}, {b0, b1}};
+        status[t] = forward_jacobian(*c, *locals[t], f, ls, -1, 0, c->nelems, &mine);
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int t = 0; t < nthreads; ++t) if (status[t] != 0) rc = -1;
   }
+  for (auto* l : locals) delete l;
   return rc;
 }
 
