@@ -208,6 +208,30 @@ class Assembler:
         return self._rc(self.L.c8_param_gradient(self.h, C.byref(st), z, C.c_void_p(phi.data_ptr()),
                                                  C.c_void_p(grad.data_ptr())))
 
+    # ---- next to the hot path: boundary conditions on the device system, y = A x ----------------------
+    def apply_dirichlet(self, dbcs, x_u, x_p, ls, is_adjoint=False):
+        """dbcs: list of (resid, eq, nodes int32 device tensor, values float64 device tensor)."""
+        d = (_l.Dbc * max(1, len(dbcs)))()
+        for k, (resid, eq, nodes, vals) in enumerate(dbcs):
+            d[k] = _l.Dbc(resid, eq, nodes.numel(), nodes.data_ptr(), vals.data_ptr())
+        x = (C.c_void_p * 2)(x_u.data_ptr(), x_p.data_ptr())
+        sy = ls.c_struct()
+        return self._rc(self.L.c8_apply_dirichlet(self.h, len(dbcs), d, x, C.byref(sy), int(is_adjoint)))
+
+    def apply_traction(self, tbcs, ls):
+        """tbcs: list of (resid, faces int32 device tensor [n][3|4], traction float64 device tensor [n][pts][3])."""
+        t = (_l.Tbc * max(1, len(tbcs)))()
+        for k, (resid, faces, tr) in enumerate(tbcs):
+            t[k] = _l.Tbc(resid, faces.shape[0], faces.shape[1], faces.data_ptr(), tr.data_ptr())
+        sy = ls.c_struct()
+        return self._rc(self.L.c8_apply_traction(self.h, len(tbcs), t, C.byref(sy)))
+
+    def apply_A(self, ls, x_u, x_p, y_u, y_p):
+        x = (C.c_void_p * 2)(x_u.data_ptr(), x_p.data_ptr())
+        y = (C.c_void_p * 2)(y_u.data_ptr(), y_p.data_ptr())
+        sy = ls.c_struct()
+        return self._rc(self.L.c8_apply_A(self.h, C.byref(sy), x, y))
+
     def eval_qoi(self, u, p, J, xi_prev=None, xi=None):
         """eval_qoi: J (1-element device tensor) += QoI value.  The local state is only needed by QoIs
         that read it ("average displacement" does not)."""

@@ -13,45 +13,21 @@
 #include "../../include/c8.h"
 #include "c8_host.hpp"
 #include "c8_kernels.hpp"
+#include "c8_api_internal.hpp"
 
 using namespace c8;
 
-static thread_local std::string g_last_error;
-static int fail(int code, std::string const& msg) {
-  g_last_error = msg;
+thread_local std::string g_c8_last_error;
+int c8_fail(int code, std::string const& msg) {
+  g_c8_last_error = msg;
   return code;
 }
+static int fail(int code, std::string const& msg) { return c8_fail(code, msg); }
 #define C8_HIP(call)                                                                               \
   do {                                                                                             \
     hipError_t err__ = (call);                                                                     \
     if (err__ != hipSuccess) return fail(C8_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(err__)); \
   } while (0)
-
-struct c8_ctx {
-  HostMesh mesh;
-  HostGraph graph;
-  std::vector<int32_t> order, color_off;
-  int model = MODEL_NONE;
-  int nloc = 0, nparams = 0, npts0 = 0;
-  ModelSettings ms{};
-  std::vector<double> params;
-  std::vector<std::vector<int32_t>> active;
-  KernelSet ks{};
-  // device mirrors
-  int32_t* d_conn = nullptr;
-  double* d_coords = nullptr;
-  int32_t* d_nodeptr = nullptr;
-  uint8_t* d_pos = nullptr;
-  int32_t* d_elem_set = nullptr;
-  int32_t* d_order = nullptr;
-  double* d_params = nullptr;
-  int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
-  int* d_status = nullptr;
-  hipStream_t stream = nullptr;
-  int scatter_mode = C8_SCATTER_COLORED;
-  int kernel_variant = C8_KERNEL_AUTO;
-  int async = 0;
-};
 
 template <class T> static int upload(T** dptr, std::vector<T> const& h) {
   if (h.empty()) { *dptr = nullptr; return C8_OK; }
@@ -85,7 +61,7 @@ static int upload_active(c8_ctx* c) {
 
 extern "C" {
 
-const char* c8_last_error(void) { return g_last_error.c_str(); }
+const char* c8_last_error(void) { return g_c8_last_error.c_str(); }
 
 int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   if (!md || !mo || !out) return fail(C8_ERR_ARG, "c8_create: null argument");
@@ -138,13 +114,13 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   c->ks = get_kernels(md->elem_type, model);
   int rc = C8_OK;
   if ((rc = upload(&c->d_conn, c->mesh.conn)) || (rc = upload(&c->d_coords, c->mesh.coords)) ||
-      (rc = upload(&c->d_nodeptr, c->graph.nodeptr)) || (rc = upload(&c->d_pos, c->graph.pos)) ||
+      (rc = upload(&c->d_nodeptr, c->graph.nodeptr)) || (rc = upload(&c->d_nodeadj, c->graph.nodeadj)) || (rc = upload(&c->d_pos, c->graph.pos)) ||
       (rc = upload(&c->d_elem_set, c->mesh.elem_set)) || (rc = upload(&c->d_order, c->order)) ||
       (rc = upload(&c->d_params, c->params)) || (rc = upload_active(c))) {
     c8_destroy(c);
     return rc;
   }
-  if (hipMalloc((void**)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
+  if (hipMalloc((void**)&c->d_scalar, sizeof(double)) != hipSuccess || hipMalloc((void**)&c->d_status, sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
     c8_destroy(c);
     return fail(C8_ERR_DEVICE, "c8_create: status allocation failed");
   }
@@ -154,7 +130,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
 
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
+  void* bufs[] = {c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }

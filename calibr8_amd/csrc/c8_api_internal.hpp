@@ -1,0 +1,45 @@
+// c8_api_internal.hpp -- the context behind the opaque c8_ctx of include/c8.h, shared by the
+// translation units that implement the C ABI.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/c8.h"
+#include "c8_host.hpp"
+#include "c8_kernels.hpp"
+
+int c8_fail(int code, std::string const& msg);  // records c8_last_error() and returns code
+
+struct c8_ctx {
+  // (namespace c8 types)
+  c8::HostMesh mesh;
+  c8::HostGraph graph;
+  std::vector<int32_t> order, color_off;
+  int model = c8::MODEL_NONE;
+  int nloc = 0, nparams = 0, npts0 = 0;
+  c8::ModelSettings ms{};
+  std::vector<double> params;
+  std::vector<std::vector<int32_t>> active;
+  c8::KernelSet ks{};
+  // device mirrors
+  int32_t* d_conn = nullptr;
+  double* d_coords = nullptr;
+  int32_t* d_nodeptr = nullptr;
+  int32_t* d_nodeadj = nullptr;   // node-graph columns (boundary conditions, A x)
+  double* d_scalar = nullptr;     // reduction result
+  double* d_work[4] = {nullptr, nullptr, nullptr, nullptr};  // Newton driver: dx[2], A dx[2]
+  uint8_t* d_pos = nullptr;
+  int32_t* d_elem_set = nullptr;
+  int32_t* d_order = nullptr;
+  double* d_params = nullptr;
+  int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
+  int* d_status = nullptr;
+  hipStream_t stream = nullptr;
+  int scatter_mode = C8_SCATTER_COLORED;
+  int kernel_variant = C8_KERNEL_AUTO;
+  int async = 0;
+};
+

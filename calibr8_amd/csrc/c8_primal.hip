@@ -1,0 +1,309 @@
+// c8_primal.hip -- next to the hot path: Dirichlet and traction boundary
+// conditions on the assembled device system, y = A x, and the Newton / line-search step driver
+// that calls the assembly.  O(boundary) kernels and host control flow; the sparse linear solve is a
+// caller-supplied callback (out of scope, linear_solve.cpp).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/c8.h"
+#include "c8_api_internal.hpp"
+
+using namespace c8;
+
+namespace {
+
+constexpr int TPB = 256;
+__host__ __device__ inline int neq_of(int i) { return i == 0 ? 3 : 1; }
+
+// dbcs.cpp:68-118: one thread per constrained row
+__global__ void k_dirichlet(int n, int resid, int eq, int32_t const* nodes, double const* values, double const* x,
+                            int32_t const* nodeptr, int32_t const* nodeadj, double* A_i0, double* A_i1, double* b,
+                            int is_adjoint) {
+  int const t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  int const node = nodes[t];
+  int const ni = neq_of(resid);
+  int const row = node * ni + eq;
+  int64_t const np = nodeptr[node], deg = nodeptr[node + 1] - np;
+  double diag = 0.;
+  for (int j = 0; j < 2; ++j) {
+    int const nj = neq_of(j);
+    double* vals = (j == 0 ? A_i0 : A_i1) + np * ni * nj + (int64_t)eq * deg * nj;  // start of this CSR row
+    for (int64_t k = 0; k < deg; ++k)
+      for (int e = 0; e < nj; ++e) {
+        bool const is_diag = (j == resid) && (nodeadj[np + k] == node) && (e == eq);
+        if (is_diag) diag = vals[k * nj + e];
+        else vals[k * nj + e] = 0.;
+      }
+  }
+  b[row] = is_adjoint ? 0. : diag * (x[row] - values[t]);
+}
+
+// tbcs.cpp:46-78: one thread per face
+__global__ void k_traction(int n, int npf, int32_t const* faces, double const* traction, double const* coords, double* b) {
+  int const f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  int32_t const* fn = faces + (size_t)f * npf;
+  double X[4][3];
+  for (int a = 0; a < npf; ++a)
+    for (int d = 0; d < 3; ++d) X[a][d] = coords[(size_t)fn[a] * 3 + d];
+  if (npf == 3) {  // order-1 rule: centroid, w = 1/2, dv = 2 * area, N = 1/3
+    double const e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
+    double const e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
+    double const cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+    double const dv = sqrt(cx * cx + cy * cy + cz * cz);
+    double const* T = traction + (size_t)f * 3;
+    for (int a = 0; a < 3; ++a)
+      for (int d = 0; d < 3; ++d) unsafeAtomicAdd(&b[(size_t)fn[a] * 3 + d], -(T[d] * (1. / 3.) * 0.5 * dv));
+  } else {  // quad4, 2x2 Gauss
+    double const g = 0.5773502691896257645;
+    for (int q = 0; q < 4; ++q) {
+      double const xi = (q & 1) ? g : -g, eta = (q & 2) ? g : -g;
+      double const sx[4] = {-1., 1., 1., -1.}, sy[4] = {-1., -1., 1., 1.};
+      double N[4], dx[3] = {0., 0., 0.}, dy[3] = {0., 0., 0.};
+      for (int a = 0; a < 4; ++a) {
+        N[a] = 0.25 * (1. + sx[a] * xi) * (1. + sy[a] * eta);
+        double const dNx = 0.25 * sx[a] * (1. + sy[a] * eta), dNy = 0.25 * sy[a] * (1. + sx[a] * xi);
+        for (int d = 0; d < 3; ++d) { dx[d] += dNx * X[a][d]; dy[d] += dNy * X[a][d]; }
+      }
+      double const cx = dx[1] * dy[2] - dx[2] * dy[1], cy = dx[2] * dy[0] - dx[0] * dy[2], cz = dx[0] * dy[1] - dx[1] * dy[0];
+      double const dv = sqrt(cx * cx + cy * cy + cz * cz);
+      double const* T = traction + ((size_t)f * 4 + q) * 3;
+      for (int a = 0; a < 4; ++a)
+        for (int d = 0; d < 3; ++d) unsafeAtomicAdd(&b[(size_t)fn[a] * 3 + d], -(T[d] * N[a] * dv));
+    }
+  }
+}
+
+// y_i[row] (+)= sum_k A_ij[row][k] x_j[col k]; one thread per row
+__global__ void k_spmv(int nnodes, int i, int j, int32_t const* nodeptr, int32_t const* nodeadj, double const* vals,
+                       double const* x, double* y, int accumulate) {
+  int const row = blockIdx.x * blockDim.x + threadIdx.x;
+  int const ni = neq_of(i), nj = neq_of(j);
+  if (row >= nnodes * ni) return;
+  int const node = row / ni, eq = row - node * ni;
+  int64_t const np = nodeptr[node], deg = nodeptr[node + 1] - np;
+  double const* v = vals + np * ni * nj + (int64_t)eq * deg * nj;
+  double s = 0.;
+  for (int64_t k = 0; k < deg; ++k) {
+    int const cn = nodeadj[np + k];
+    for (int e = 0; e < nj; ++e) s += v[k * nj + e] * x[(size_t)cn * nj + e];
+  }
+  y[row] = accumulate ? y[row] + s : s;
+}
+
+__global__ void k_axpy(size_t n, double a, double const* x, double* y) {
+  size_t const t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t < n) y[t] += a * x[t];
+}
+__global__ void k_scale(size_t n, double a, double* y) {
+  size_t const t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t < n) y[t] *= a;
+}
+__global__ void k_dot(size_t n, double const* x, double const* y, double* out) {
+  __shared__ double sm[TPB / 64];
+  double s = 0.;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) s += x[t] * y[t];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.;
+    for (int w = 0; w < TPB / 64; ++w) tot += sm[w];
+    unsafeAtomicAdd(out, tot);
+  }
+}
+
+int grid_of(size_t n) { return (int)((n + TPB - 1) / TPB); }
+
+}  // namespace
+
+#define C8P_HIP(call)                                                                                                   \
+  do {                                                                                                                  \
+    hipError_t err__ = (call);                                                                                          \
+    if (err__ != hipSuccess) return c8_fail(C8_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(err__));       \
+  } while (0)
+
+static int dot(c8_ctx* c, size_t n, double const* x, double const* y, double* result) {
+  C8P_HIP(hipMemsetAsync(c->d_scalar, 0, sizeof(double), c->stream));
+  int const g = std::min(grid_of(n), 1024);
+  hipLaunchKernelGGL(k_dot, dim3(g), dim3(TPB), 0, c->stream, n, x, y, c->d_scalar);
+  C8P_HIP(hipMemcpyAsync(result, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  C8P_HIP(hipStreamSynchronize(c->stream));
+  return C8_OK;
+}
+
+extern "C" {
+
+int c8_apply_dirichlet(c8_ctx* c, int n, const c8_dbc* dbcs, const double* const x[2], const c8_system* sys, int is_adjoint) {
+  if (!c || n < 0 || (n > 0 && !dbcs) || !x || !sys) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: null argument");
+  for (int q = 0; q < n; ++q) {  // in deck order: later conditions overwrite earlier ones on shared rows
+    c8_dbc const& d = dbcs[q];
+    if (d.resid < 0 || d.resid > 1 || d.eq < 0 || d.eq >= neq_of(d.resid)) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: bad residual/equation index");
+    if (d.n <= 0) continue;
+    hipLaunchKernelGGL(k_dirichlet, dim3(grid_of(d.n)), dim3(TPB), 0, c->stream, d.n, d.resid, d.eq, d.nodes, d.values,
+                       x[d.resid], c->d_nodeptr, c->d_nodeadj, sys->A[d.resid][0], sys->A[d.resid][1], sys->b[d.resid], is_adjoint);
+    C8P_HIP(hipGetLastError());
+  }
+  return C8_OK;
+}
+
+int c8_apply_traction(c8_ctx* c, int n, const c8_tbc* tbcs, const c8_system* sys) {
+  if (!c || n < 0 || (n > 0 && !tbcs) || !sys) return c8_fail(C8_ERR_ARG, "c8_apply_traction: null argument");
+  for (int q = 0; q < n; ++q) {
+    c8_tbc const& t = tbcs[q];
+    if (t.resid != 0 || (t.nodes_per_face != 3 && t.nodes_per_face != 4)) return c8_fail(C8_ERR_ARG, "c8_apply_traction: tractions act on residual 0 over tri3/quad4 faces");
+    if (t.n <= 0) continue;
+    hipLaunchKernelGGL(k_traction, dim3(grid_of(t.n)), dim3(TPB), 0, c->stream, t.n, t.nodes_per_face, t.faces, t.traction,
+                       c->d_coords, sys->b[0]);
+    C8P_HIP(hipGetLastError());
+  }
+  return C8_OK;
+}
+
+int c8_face_points(int npf, int n, const double* coords, const int32_t* faces, double* xyz) {
+  if ((npf != 3 && npf != 4) || n < 0 || !coords || !faces || !xyz) return c8_fail(C8_ERR_ARG, "c8_face_points: bad argument");
+  double const g = 0.5773502691896257645;
+  for (int f = 0; f < n; ++f) {
+    int32_t const* fn = faces + (size_t)f * npf;
+    if (npf == 3) {
+      for (int d = 0; d < 3; ++d)
+        xyz[(size_t)f * 3 + d] = (coords[(size_t)fn[0] * 3 + d] + coords[(size_t)fn[1] * 3 + d] + coords[(size_t)fn[2] * 3 + d]) / 3.;
+    } else {
+      double const sx[4] = {-1., 1., 1., -1.}, sy[4] = {-1., -1., 1., 1.};
+      for (int q = 0; q < 4; ++q) {
+        double const xi = (q & 1) ? g : -g, eta = (q & 2) ? g : -g;
+        for (int d = 0; d < 3; ++d) {
+          double s = 0.;
+          for (int a = 0; a < 4; ++a) s += 0.25 * (1. + sx[a] * xi) * (1. + sy[a] * eta) * coords[(size_t)fn[a] * 3 + d];
+          xyz[((size_t)f * 4 + q) * 3 + d] = s;
+        }
+      }
+    }
+  }
+  return C8_OK;
+}
+
+int c8_apply_A(c8_ctx* c, const c8_system* sys, const double* const x[2], double* const y[2]) {
+  if (!c || !sys || !x || !y) return c8_fail(C8_ERR_ARG, "c8_apply_A: null argument");
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      hipLaunchKernelGGL(k_spmv, dim3(grid_of((size_t)c->mesh.nnodes * neq_of(i))), dim3(TPB), 0, c->stream, c->mesh.nnodes, i, j,
+                         c->d_nodeptr, c->d_nodeadj, sys->A[i][j], x[j], y[i], j);
+      C8P_HIP(hipGetLastError());
+    }
+  return C8_OK;
+}
+
+int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs, int ntbc,
+                         const c8_tbc* tbcs, const c8_newton_opts* o, c8_linear_solve_fn solve, void* user, int32_t* iters_out) {
+  if (!c || !st || !sys || !o || !solve) return c8_fail(C8_ERR_ARG, "c8_primal_solve_step: null argument");
+  size_t const n[2] = {(size_t)c->mesh.nnodes * 3, (size_t)c->mesh.nnodes};
+  size_t nnz[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) nnz[i][j] = (size_t)c->graph.nodeptr[c->mesh.nnodes] * neq_of(i) * neq_of(j);
+  if (!c->d_work[0]) {
+    for (int k = 0; k < 4; ++k) C8P_HIP(hipMalloc((void**)&c->d_work[k], n[k & 1] * sizeof(double)));
+  }
+  double* dx[2] = {c->d_work[0], c->d_work[1]};
+  double* Adx[2] = {c->d_work[2], c->d_work[3]};
+  double* x[2] = {const_cast<double*>(st->x[0]), const_cast<double*>(st->x[1])};
+  int const saved_async = c->async;
+
+  // la->zero_all + eval_forward_jacobian + tbcs + dbcs (primal.cpp:97-114); returns the assembly status
+  auto assemble = [&]() -> int {
+    for (int i = 0; i < 2; ++i) {
+      if (hipMemsetAsync(sys->b[i], 0, n[i] * sizeof(double), c->stream) != hipSuccess) return C8_ERR_DEVICE;
+      for (int j = 0; j < 2; ++j)
+        if (hipMemsetAsync(sys->A[i][j], 0, nnz[i][j] * sizeof(double), c->stream) != hipSuccess) return C8_ERR_DEVICE;
+    }
+    c->async = 0;
+    int rc = c8_assemble_forward_jacobian(c, st, sys);
+    c->async = saved_async;
+    if (rc != C8_OK) return rc;
+    if ((rc = c8_apply_traction(c, ntbc, tbcs, sys)) != C8_OK) return rc;
+    return c8_apply_dirichlet(c, ndbc, dbcs, st->x, sys, 0);
+  };
+  auto norm_b = [&](double* out) -> int {  // LinearAlg::norm_b, linear_alg.cpp:138-146
+    double s0 = 0., s1 = 0.;
+    int rc;
+    if ((rc = dot(c, n[0], sys->b[0], sys->b[0], &s0)) != C8_OK) return rc;
+    if ((rc = dot(c, n[1], sys->b[1], sys->b[1], &s1)) != C8_OK) return rc;
+    *out = std::sqrt(s0 + s1);
+    return C8_OK;
+  };
+  auto add_to_soln = [&](double alpha) {  // Disc::add_to_soln(x, dx, alpha), disc.cpp:893-949
+    for (int i = 0; i < 2; ++i)
+      hipLaunchKernelGGL(k_axpy, dim3(grid_of(n[i])), dim3(TPB), 0, c->stream, n[i], alpha, dx[i], x[i]);
+  };
+
+  int iter = 1;
+  bool converged = false;
+  double resid_norm_0 = 1.;
+  int rc = C8_OK;
+  while ((iter <= o->max_iters) && !converged) {
+    rc = assemble();
+    if (rc != C8_OK) break;  // local solve failed at the base point (primal.cpp:101-104), or an error
+    double abs_resid_norm;
+    if ((rc = norm_b(&abs_resid_norm)) != C8_OK) break;
+    if (iter == 1) resid_norm_0 = abs_resid_norm;
+    double const rel_resid_norm = abs_resid_norm / resid_norm_0;
+    if ((abs_resid_norm < o->abs_tol) || (rel_resid_norm < o->rel_tol)) { converged = true; break; }
+    for (int i = 0; i < 2; ++i)  // la->scale_b(-1.)
+      hipLaunchKernelGGL(k_scale, dim3(grid_of(n[i])), dim3(TPB), 0, c->stream, n[i], -1., sys->b[i]);
+    C8P_HIP(hipStreamSynchronize(c->stream));
+    if (solve(user, sys, dx) != 0) { rc = c8_fail(C8_ERR_ARG, "c8_primal_solve_step: linear solve callback failed"); break; }
+    add_to_soln(1.);
+    if (o->line_search) {  // primal.cpp:139-197 with line_search.hpp:85-135
+      double const psi_0 = 0.5 * abs_resid_norm * abs_resid_norm, dpsi_0 = -2. * psi_0;
+      double const armijo_slope = o->sufficient_decrease * dpsi_0;
+      double alpha_applied = 1., alpha = 1., best_alpha = 1., best_phi = std::numeric_limits<double>::max();
+      bool assembled_any = false, accepted = false;
+      for (int ev = 1; ev <= o->max_evals; ++ev) {
+        add_to_soln(alpha - alpha_applied);
+        alpha_applied = alpha;
+        int const arc = assemble();
+        if (arc == C8_LOCAL_SOLVE_FAILED) { alpha *= 0.5; continue; }  // failed evaluation: halve and retry
+        if (arc != C8_OK) { rc = arc; break; }
+        double R_alpha;
+        if ((rc = norm_b(&R_alpha)) != C8_OK) break;
+        double const phi = 0.5 * R_alpha * R_alpha;
+        assembled_any = true;
+        if (phi < best_phi) { best_phi = phi; best_alpha = alpha; }
+        if (phi <= psi_0 + alpha * armijo_slope) { accepted = true; break; }
+        // slope phi'(alpha) = R(alpha) . (A dx) for the Hermite cubic
+        const double* cdx[2] = {dx[0], dx[1]};
+        if ((rc = c8_apply_A(c, sys, cdx, Adx)) != C8_OK) break;
+        double s0 = 0., s1 = 0.;
+        if ((rc = dot(c, n[0], sys->b[0], Adx[0], &s0)) != C8_OK || (rc = dot(c, n[1], sys->b[1], Adx[1], &s1)) != C8_OK) break;
+        double const slope = s0 + s1;
+        double const d1 = dpsi_0 + slope - 3. * (psi_0 - phi) / (0. - alpha);
+        double const radicand = d1 * d1 - dpsi_0 * slope;
+        double alpha_model = 0.5 * alpha;
+        if (radicand >= 0.) {
+          double const d2 = std::sqrt(radicand), denom = slope - dpsi_0 + 2. * d2;
+          if (denom != 0.) alpha_model = alpha - alpha * (slope + d2 - d1) / denom;
+        }
+        alpha = std::min(std::max(alpha_model, o->min_backtrack * alpha), o->max_backtrack * alpha);
+      }
+      if (rc != C8_OK) break;
+      if (!accepted) {
+        if (!assembled_any) { rc = c8_fail(C8_LOCAL_SOLVE_FAILED, "line search could not assemble at any trial step"); break; }
+        alpha = best_alpha;
+      }
+      add_to_soln(alpha - alpha_applied);
+    }
+    iter++;
+  }
+  C8P_HIP(hipStreamSynchronize(c->stream));
+  if (iters_out) *iters_out = iter;
+  if (rc != C8_OK) return rc;
+  if (!converged) return c8_fail(C8_NOT_CONVERGED, "Newton's method failed in the allowed iterations");
+  return C8_OK;
+}
+
+}  // extern "C"

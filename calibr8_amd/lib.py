@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libc8.so")
 
 C8_ELEM_TET4, C8_ELEM_HEX8 = 4, 8
-C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED, C8_NOT_CONVERGED = 0, -1, -2, -3, -4, -5
 C8_SCATTER_ATOMIC, C8_SCATTER_COLORED = 0, 1
 C8_KERNEL_AUTO, C8_KERNEL_SLOT, C8_KERNEL_WAVE = 0, 1, 2
 
@@ -33,6 +33,21 @@ class ModelDesc(C.Structure):
                 ("num_params", C.c_int32), ("params", dp)]
 
 
+class Dbc(C.Structure):
+    _fields_ = [("resid", C.c_int32), ("eq", C.c_int32), ("n", C.c_int32), ("nodes", C.c_void_p), ("values", C.c_void_p)]
+
+
+class Tbc(C.Structure):
+    _fields_ = [("resid", C.c_int32), ("n", C.c_int32), ("nodes_per_face", C.c_int32), ("faces", C.c_void_p),
+                ("traction", C.c_void_p)]
+
+
+class NewtonOpts(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("abs_tol", C.c_double), ("rel_tol", C.c_double), ("line_search", C.c_int32),
+                ("sufficient_decrease", C.c_double), ("min_backtrack", C.c_double), ("max_backtrack", C.c_double),
+                ("max_evals", C.c_int32)]
+
+
 class State(C.Structure):
     _fields_ = [("x", C.c_void_p * 2), ("x_prev", C.c_void_p * 2), ("xi_prev", C.c_void_p), ("xi", C.c_void_p)]
 
@@ -40,6 +55,8 @@ class State(C.Structure):
 class System(C.Structure):
     _fields_ = [("A", (C.c_void_p * 2) * 2), ("b", C.c_void_p * 2)]
 
+
+LINEAR_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(System), C.POINTER(C.c_void_p))
 
 # every symbol include/c8.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -66,6 +83,12 @@ SYMBOLS = [
     ("c8_solve_adjoint_local", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("c8_param_gradient", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     ("c8_eval_qoi", C.c_int, [C.c_void_p, C.POINTER(State), C.c_void_p]),
+    ("c8_apply_dirichlet", C.c_int, [C.c_void_p, C.c_int, C.POINTER(Dbc), C.POINTER(C.c_void_p), C.POINTER(System), C.c_int]),
+    ("c8_apply_traction", C.c_int, [C.c_void_p, C.c_int, C.POINTER(Tbc), C.POINTER(System)]),
+    ("c8_face_points", C.c_int, [C.c_int, C.c_int, dp, i32p, dp]),
+    ("c8_apply_A", C.c_int, [C.c_void_p, C.POINTER(System), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("c8_primal_solve_step", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System), C.c_int, C.POINTER(Dbc), C.c_int,
+                                       C.POINTER(Tbc), C.POINTER(NewtonOpts), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     ("c8_brick_mesh", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, i32p]),
     ("c8_brick_partition", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
 ]

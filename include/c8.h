@@ -139,6 +139,53 @@ int c8_param_gradient(c8_ctx* ctx, const c8_state* st, const double* const z[2],
 /* eval_qoi (evaluations.cpp:662-756), "average displacement" (avg_disp.cpp:16-33): *J += value. */
 int c8_eval_qoi(c8_ctx* ctx, const c8_state* st, double* J);
 
+/* ---- next to the hot path: boundary conditions and the Newton step driver ----- */
+/* One Dirichlet condition = one entry of the deck's `dirichlet bcs` block (dbcs.cpp:59-66): residual
+ * index, equation, node set, and the prescribed value at every node of the set (the caller evaluates
+ * the expression or reads the measured field, dbcs.cpp:76 / :183-185).  DEVICE pointers. */
+typedef struct {
+  int32_t resid, eq, n;
+  const int32_t* nodes;   /* [n] local node ids */
+  const double* values;   /* [n] */
+} c8_dbc;
+/* One traction condition (tbcs.cpp:17-86) on boundary faces: tri3 faces of tet4 meshes with the
+ * reference's 1-point rule, quad4 faces of hex8 meshes with the 2x2 rule.  DEVICE pointers. */
+typedef struct {
+  int32_t resid, n, nodes_per_face;  /* 3 or 4 */
+  const int32_t* faces;    /* [n][nodes_per_face] local node ids */
+  const double* traction;  /* [n][points][3], points = 1 (tri3) or 4 (quad4) */
+} c8_tbc;
+/* apply_primal_dbcs (dbcs.cpp:28-121): for every constrained row keep the diagonal entry, zero the rest
+ * of the row in every block, b[row] = diag * (x[row] - value), or 0 when is_adjoint. */
+int c8_apply_dirichlet(c8_ctx* ctx, int n, const c8_dbc* dbcs, const double* const x[2], const c8_system* sys, int is_adjoint);
+/* apply_primal_tbcs (tbcs.cpp:88-98): b[row(node, d)] -= T_d N_node w dv over the faces. */
+int c8_apply_traction(c8_ctx* ctx, int n, const c8_tbc* tbcs, const c8_system* sys);
+/* Integration points of boundary faces (HOST arrays): xyz [n][points][3], for evaluating traction expressions. */
+int c8_face_points(int nodes_per_face, int n, const double* coords, const int32_t* faces, double* xyz);
+/* LinearAlg::apply_A (linear_alg.cpp:158-175): y = A x over the four blocks (DEVICE pointers). */
+int c8_apply_A(c8_ctx* ctx, const c8_system* sys, const double* const x[2], double* const y[2]);
+
+/* The linear solve is out of scope (Belos/Teko/MueLu in the reference, linear_solve.cpp): the driver
+ * calls back with the assembled system (b already scaled to -R, primal.cpp:131) and device arrays to
+ * receive dx.  Return 0 on success. */
+typedef int (*c8_linear_solve_fn)(void* user, const c8_system* sys, double* const dx[2]);
+typedef struct {
+  int32_t max_iters;            /* "nonlinear max iters" of the global residual */
+  double abs_tol, rel_tol;      /* "nonlinear absolute/relative tol" */
+  int32_t line_search;          /* 1 = Armijo/cubic backtracking (line_search.hpp), 0 = full steps */
+  double sufficient_decrease;   /* 1e-4 */
+  double min_backtrack, max_backtrack; /* 0.5, 0.9 */
+  int32_t max_evals;            /* 4 */
+} c8_newton_opts;
+/* Primal::solve_at_step (primal.cpp:31-209) for one part: Newton iterations on st->x (updated in place,
+ * st->xi receives the converged local state) with the reference's convergence tests and line search.
+ * Returns C8_OK, C8_LOCAL_SOLVE_FAILED (base point or every line-search trial failed), or
+ * C8_NOT_CONVERGED; *iters = Newton iterations taken. */
+enum { C8_NOT_CONVERGED = -5 };
+int c8_primal_solve_step(c8_ctx* ctx, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs, int ntbc,
+                         const c8_tbc* tbcs, const c8_newton_opts* opts, c8_linear_solve_fn solve, void* user,
+                         int32_t* iters);
+
 /* ---- host helpers for synthetic problems -------------------------------- */
 /* Structured hex8 brick; coords [(nx+1)(ny+1)(nz+1)][3], conn [nx*ny*nz][8] (host arrays). */
 int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, double* coords, int32_t* conn);

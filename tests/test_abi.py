@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "c8.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(c8_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(c8_[A-Za-z_0-9]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,132 @@
+"""`-m gpu`: the rows next to the hot path on the device -- Dirichlet and traction
+boundary conditions, y = A x, and the C++ Newton / line-search driver -- against the test-side
+restatements in fe_driver.py and the reference's regression values."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from fe_driver import Dbc, Primal, Tbc, apply_dbcs, apply_tbcs, block_matrix
+from meshes import brick, jiggle, prescribed_fields
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+
+
+def cube():
+    d = json.load(open(os.path.join(HERE, "golden", "cube_tet4.json")))
+    return np.array(d["coords"]), np.array(d["conn"], dtype=np.int32), d["node_sets"], d["side_sets"]
+
+
+def test_boundary_conditions_and_matvec_match_host_restatement():
+    import torch
+    from gpu_backend import GpuBackend
+    for kind in ("tet4", "hex8"):
+        if kind == "tet4":
+            c, conn, ns, ss = cube()
+            et, model, params = ol.TET4, "elastic", [1000.0, 0.25, 1e-3, 10.0]
+            sets = {k: np.array(v) for k, v in ns.items()}
+            faces = np.array(ss["ymax"], dtype=np.int32)
+        else:
+            c, conn, sets = brick(4, 3, 3, 1.0, 0.8, 0.7)
+            c = jiggle(c, sets, 0.03)
+            et, model, params = ol.HEX8, "small_J2", J2
+            # quad faces of the ymax side: nodes of each boundary element face
+            faces = np.array([[e[3], e[2], e[6], e[7]] for e in conn if np.isin(e[[3, 2, 6, 7]], sets["ymax"]).all()],
+                             dtype=np.int32)
+        g = GpuBackend(et, c, conn, model, params)
+        a = g.asm
+        u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+        z, zp = np.zeros_like(u), np.zeros_like(p)
+        ls_h = g.new_linsys()
+        assert g.forward_jacobian(u, p, z, zp, g.new_state(), g.new_state(), ls_h) == 0
+        d = a.new_linsys()
+        for i in range(2):
+            d.b[i].copy_(a.dev(ls_h.b[i]))
+            for j in range(2):
+                d.A[i][j].copy_(a.dev(ls_h.A[i][j]))
+        # host restatement
+        fn1 = lambda x, y, zz, t: 0.01 * t + 0.1 * x
+        trac = lambda x, y, zz, t: (0.3 * t, 0.1 * t + y, -0.2 * x)
+        dbcs = [Dbc(0, 0, sets["xmin"], lambda x, y, zz, t: 0.0), Dbc(0, 1, sets["ymin"], fn1), Dbc(1, 0, sets["zmin"], fn1)]
+        t = 2.0
+        if kind == "tet4":
+            apply_tbcs(ls_h, [Tbc(0, faces.tolist(), trac)], c, t)
+        apply_dbcs(g, ls_h, dbcs, [u, p], c, t)
+        # device
+        import calibr8_amd.lib as L
+        npf = faces.shape[1]
+        pts = np.zeros((len(faces), 1 if npf == 3 else 4, 3))
+        L.check(a.L.c8_face_points(npf, len(faces), a.coords.ctypes.data_as(L.dp), faces.ctypes.data_as(L.i32p), pts.ctypes.data_as(L.dp)))
+        tr = np.array([[trac(x, y, zz, t) for x, y, zz in fp] for fp in pts])
+        if kind == "tet4":
+            a.apply_traction([(0, torch.as_tensor(faces, device=a.device), a.dev(tr.ravel()))], d)
+        dd = [(b.resid, b.eq, torch.as_tensor(np.asarray(b.nodes, dtype=np.int32), device=a.device),
+               a.dev(np.array([b.fn(*c[n], t) for n in b.nodes]))) for b in dbcs]
+        a.apply_dirichlet(dd, a.dev(u), a.dev(p), d)
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert np.abs(d.b[i].cpu().numpy() - ls_h.b[i]).max() <= 1e-13 * max(1.0, np.abs(ls_h.b[i]).max())
+            for j in range(2):
+                assert np.array_equal(d.A[i][j].cpu().numpy(), ls_h.A[i][j])
+        if kind == "hex8":  # quad4 traction: constant traction integrates to T * area, spread over the face nodes
+            d.b[0].zero_()
+            a.apply_traction([(0, torch.as_tensor(faces, device=a.device), a.dev(np.tile([0.0, 2.0, 0.0], len(faces) * 4)))], d)
+            by = d.b[0].cpu().numpy().reshape(-1, 3)
+            assert abs(by[:, 1].sum() + 2.0 * 1.0 * 0.7) < 1e-12 and np.abs(by[:, [0, 2]]).max() == 0.0
+        # y = A x
+        rng = np.random.default_rng(1)
+        xu, xp = rng.standard_normal(len(u)), rng.standard_normal(len(p))
+        yu, yp = a.dev(np.zeros_like(u)), a.dev(np.zeros_like(p))
+        a.apply_A(d, a.dev(xu), a.dev(xp), yu, yp)
+        ref = block_matrix(g, ls_h) @ np.concatenate([xu, xp])
+        got = np.concatenate([yu.cpu().numpy(), yp.cpu().numpy()])
+        assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("deck", ["cube_elastic", "cube_hyper_J2", "cube_hyperelasticity_traction"])
+def test_reference_regressions_with_device_newton_driver(deck):
+    # the reference's primal regression decks (test/primal/*.yaml.in) run end to end through
+    # c8_primal_solve_step: HIP assembly + device boundary conditions + C++ Newton/line search
+    from calibr8_amd import Assembler, PrimalDriver
+    c, conn, ns, ss = cube()
+    zero = lambda x, y, z, t: 0.0
+    sym = [(0, 0, ns["xmin"], zero), (0, 1, ns["ymin"], zero), (0, 2, ns["zmin"], zero)]
+    if deck == "cube_elastic":
+        asm = Assembler(4, c, conn, "elastic", [1000.0, 0.25, 1e-3, 10.0])
+        pr = PrimalDriver(asm, sym).solve(1)
+        expected, tol = 5.00000000000000184e-3, 1e-6
+    elif deck == "cube_hyper_J2":
+        asm = Assembler(4, c, conn, "hyper_J2", [1000.0, 0.25, 10.0, 0.0, 0.0, 0.0, 0.0, 100.0], max_iters=30)
+        pr = PrimalDriver(asm, sym + [(0, 1, ns["ymax"], lambda x, y, z, t: 0.01 * t)]).solve(10)
+        expected, tol = 1.57817536611772440e-02, 1e-4
+    else:
+        asm = Assembler(4, c, conn, "hyper_J2", [1000.0, 0.25, 100000.0, 0.0, 0.0, 0.0, 0.0, 100.0], max_iters=30)
+        clamp = [(0, d, ns["ymin"], zero) for d in range(3)]
+        pr = PrimalDriver(asm, clamp, [(0, np.array(ss["ymax"], dtype=np.int32), lambda x, y, z, t: (0.0, 0.1 * t, 0.0))],
+                          max_iters=10).solve(4)
+        expected, tol = 1.61757374785081228e-04, 1e-4
+    assert abs(pr.qoi() / expected - 1) < tol, (pr.qoi(), pr.newton_iters)
+
+
+def test_device_newton_driver_matches_oracle_driven_newton():
+    # same problem, Newton history and solution: C++ driver on the GPU vs the Python driver on the oracle
+    from calibr8_amd import Assembler, PrimalDriver
+    c, conn, sets = brick(3, 4, 3, 1.0, 1.5, 1.0)
+    c = jiggle(c, sets, 0.05)
+    zero = lambda x, y, z, t: 0.0
+    pull = lambda x, y, z, t: 0.003 * t
+    spec = [(0, 0, sets["ymin"], zero), (0, 1, sets["ymin"], zero), (0, 2, sets["ymin"], zero),
+            (0, 1, sets["ymax"], pull), (0, 0, sets["ymax"], zero)]
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+    ref = Primal(orc, c, [Dbc(*s) for s in spec], max_iters=15, abs_tol=1e-10, rel_tol=1e-10).solve(3)
+    asm = Assembler(8, c, conn, "small_J2", J2)
+    pr = PrimalDriver(asm, spec, max_iters=15, abs_tol=1e-10, rel_tol=1e-10).solve(3)
+    assert pr.newton_iters == ref.newton_iters
+    for s in range(1, 4):
+        assert np.abs(pr.u[s].cpu().numpy() - ref.u[s]).max() < 1e-10 * np.abs(ref.u[s]).max()
+        assert np.abs(pr.xi[s].cpu().numpy() - ref.xi[s]).max() < 1e-10
+    assert abs(pr.qoi() - ref.qoi()) < 1e-12
