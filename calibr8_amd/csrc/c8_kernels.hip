@@ -20,10 +20,20 @@ template <class Lane> struct GpuExec {
   __device__ __forceinline__ Lane& lane(int) { return L; }
   template <class F> __device__ __forceinline__ bool any(F f) { return f(k); }
   template <class F> __device__ __forceinline__ bool any_wave(F f) { return __any(f(k)) != 0; }
+  // Lanes of one wavefront exchange data through LDS.  LDS instructions of a wave execute in order, so
+  // only the compiler has to be kept from moving LDS accesses across the exchange point: a
+  // wavefront-scope fence does that without draining the memory counters (a workgroup-scope fence
+  // also waits for outstanding global loads/stores/atomics).
   __device__ __forceinline__ void sync() {
+#ifdef C8_SYNC_WORKGROUP
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
   }
   __device__ __forceinline__ void add(double* p, double v, int atomic) {
     if (atomic) unsafeAtomicAdd(p, v);  // global_atomic_add_f64
