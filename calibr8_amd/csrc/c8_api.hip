@@ -289,13 +289,17 @@ int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const
 int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[2], double* phi, double* g, double* f) {
   if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !g || !f) return fail(C8_ERR_ARG, "c8_solve_adjoint_local: null argument");
   AdjointArgs aa{g, f, z[0], z[1], phi, nullptr, c->d_active};
-  return run(c, c->ks.adjoint_local, field_args(st), aa, SystemArgs{}, false, "c8_solve_adjoint_local");
+  LaunchFn fn = c->ks.adjoint_local;
+  if (c->ks.adjoint_local_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.adjoint_local_wave;
+  return run(c, fn, field_args(st), aa, SystemArgs{}, false, "c8_solve_adjoint_local");
 }
 
 int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], const double* phi, double* grad) {
   if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !grad) return fail(C8_ERR_ARG, "c8_param_gradient: null argument");
   AdjointArgs aa{nullptr, nullptr, z[0], z[1], const_cast<double*>(phi), grad, c->d_active};
-  return run(c, c->ks.param_gradient, field_args(st), aa, SystemArgs{}, false, "c8_param_gradient");
+  LaunchFn fn = c->ks.param_gradient;
+  if (c->ks.param_gradient_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.param_gradient_wave;
+  return run(c, fn, field_args(st), aa, SystemArgs{}, false, "c8_param_gradient");
 }
 
 int c8_eval_qoi(c8_ctx* c, const c8_state* st, double* J) {

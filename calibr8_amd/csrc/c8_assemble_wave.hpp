@@ -509,4 +509,272 @@ C8_HD void adjoint_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, 
   jacobian_wave<E, ModelT, QoI, true>(ex, sh, mt, ms, fa, aa, sa, e);
 }
 
+// =====================================================================================
+// K4 / K5 with one wavefront per element: lane = point*8 + direction, all 8 coupled points at once.
+// =====================================================================================
+template <class E, int NL> struct WaveSharedA {
+  static constexpr int NLP = 8;
+  double X[E::NN][3];
+  double u[E::NN][3], p[E::NN];
+  double u_prev[E::NN][3];
+  double N[E::NP0][E::NN];
+  double dN[E::NP0][E::NN][3];
+  double wdv[E::NP0];
+  double M[E::NP0][NLP][NLP + 1];
+  double q[E::NP0][WQ];
+  double qprev[E::NP0][9];
+  double xi[E::NP0][NLP];
+  double xip[E::NP0][NLP];
+  double z[E::NDOF];                // element adjoint solution, slot order
+  double zq[E::NP0][WQ];            // the adjoint field interpolated like q: grad z_u (0..8), z_p (9), grad z_p (10..12)
+  double vec[E::NP0][NLP];          // right-hand side / phi exchange
+  double wq[E::NP0][WQ];            // (dC/dq_prev)^T phi per point
+  double h;
+  int32_t node[E::NN];
+  int32_t nptr[E::NN], deg[E::NN];
+  int32_t failed;
+};
+
+template <template <class> class ModelT> struct WaveLaneA {
+  using Model = ModelT<Dual>;
+  Model m;
+  PointState<Dual> g;
+  double b[Model::NLOC];
+  double acc;
+  int slot;
+};
+
+// interpolate the adjoint nodal values like the point quantities (same B matrix)
+template <class E, class SH> C8_HD double interp_zq(SH const& sh, int pt, int c) {
+  double s = 0.;
+  if (c < 9) {
+    int const i = c / 3, l = c - 3 * i;
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += sh.z[3 * n + i] * sh.dN[pt][n][l];
+  } else if (c == 9) {
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += sh.z[3 * E::NN + n] * sh.N[pt][n];
+  } else if (c < 13) {
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) s += sh.z[3 * E::NN + n] * sh.dN[pt][n][c - 10];
+  }
+  return s;
+}
+
+// (d flux / ds) . (interpolated adjoint) for the tangent s carried by f: the point form of (dR/ds)^T z
+template <class SH> C8_HD double flux_dot_zq(SH const& sh, int pt, MechFlux<Dual> const& f) {
+  double const* z = sh.zq[pt];
+  double s = f.Vp.d * z[9] + f.Gp[0].d * z[10] + f.Gp[1].d * z[11] + f.Gp[2].d * z[12];
+  s += f.Gu.xx.d * z[0] + f.Gu.xy.d * z[1] + f.Gu.xz.d * z[2];
+  s += f.Gu.yx.d * z[3] + f.Gu.yy.d * z[4] + f.Gu.yz.d * z[5];
+  s += f.Gu.zx.d * z[6] + f.Gu.zy.d * z[7] + f.Gu.zz.d * z[8];
+  return s * sh.wdv[pt];
+}
+
+// common prologue: nodal data, shape tables, point quantities, adjoint point quantities, local state
+template <class E, int NL, bool PREV, class EX, class SH>
+C8_HD void wave_prologue(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& fa, AdjointArgs const& aa, int e) {
+  ex.each([&](int lane) {
+    if (lane == 0) sh.failed = 0;
+    if (lane < E::NDOF) {
+      int i, n, eq;
+      slot_to_dof<E>(lane, i, n, eq);
+      int const node = mt.conn[e * E::NN + n];
+      if (i == 0) {
+        sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
+        sh.u[n][eq] = fa.u[(size_t)node * 3 + eq];
+        if (PREV) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * 3 + eq];
+        sh.z[lane] = aa.z_u[(size_t)node * 3 + eq];
+      } else {
+        sh.p[n] = fa.p[node];
+        sh.node[n] = node;
+        sh.z[lane] = aa.z_p[node];
+      }
+    }
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
+    if (lane == 0) sh.h = elem_size<E>(sh);
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    int const pt = lane >> 3, d = lane & 7;
+    sh.q[pt][2 * d] = interp_q<E>(sh, pt, 2 * d, false);
+    sh.q[pt][2 * d + 1] = interp_q<E>(sh, pt, 2 * d + 1, false);
+    sh.zq[pt][2 * d] = interp_zq<E>(sh, pt, 2 * d);
+    sh.zq[pt][2 * d + 1] = interp_zq<E>(sh, pt, 2 * d + 1);
+    if (PREV) {
+      sh.qprev[pt][d] = interp_q<E>(sh, pt, d, true);
+      if (d == 0) sh.qprev[pt][8] = interp_q<E>(sh, pt, 8, true);
+    }
+    if (d < NL) {
+      size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+      sh.xip[pt][d] = fa.xi_prev[q + d];
+      sh.xi[pt][d] = fa.xi[q + d];
+    }
+  });
+  ex.sync();
+}
+
+// K4: solve_adjoint_local (evaluations.cpp:528-659)
+template <class E, template <class> class ModelT, class EX>
+C8_HD void adjoint_local_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, ModelSettings const& ms,
+                              FieldArgs const& fa, AdjointArgs const& aa, SystemArgs const& sa, int e) {
+  using Model = ModelT<Dual>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  static_assert(E::NDOF == 32 && E::NP0 == 8, "wave kernel needs a hex8-like element");
+  if (!Model::HAS_LOCAL) {  // dC/dxi = 0: Eigen's rank-0 solve gives phi = 0, hence f = g = 0
+    ex.each([&](int lane) {
+      int const pt = lane >> 3, d = lane & 7;
+      size_t const qp = (size_t)e * E::NP0 + pt;
+      if (d < NL) { aa.phi[qp * NL + d] = 0.; aa.g[qp * NL + d] = 0.; }
+      C8_UNROLL
+      for (int t = 0; t < 4; ++t) aa.f[(size_t)e * E::NP0 * E::NDOF + t * 64 + lane] = 0.;
+    });
+    return;
+  }
+  wave_prologue<E, NL, PREV>(ex, sh, mt, fa, aa, e);
+  // xi seeded: (dR/dxi)^T z and dC/dxi^T; rhs = g - (dR/dxi)^T z  (:613-622)
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const pt = lane >> 3, d = lane & 7;
+    size_t const qp = (size_t)e * E::NP0 + pt;
+    load_params(r.m, mt, e);
+    load_point(sh, pt, r.g, PREV);
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) {
+      r.m.xi_prev[j] = Dual(sh.xip[pt][j]);
+      r.m.xi[j] = Dual(sh.xi[pt][j], (j == d) ? 1. : 0.);
+      r.m.R[j] = Dual(0.);
+    }
+    MechFlux<Dual> f;
+    Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+    double const dRz = flux_dot_zq(sh, pt, f);
+    r.m.evaluate(r.g, ms.abs_tol);
+    if (d < NL) {
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) sh.M[pt][d][j] = r.m.R[j].d;  // transposed fill
+      sh.vec[pt][d] = aa.g[qp * NL + d] - dRz;
+    }
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const pt = lane >> 3;
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) r.b[j] = sh.vec[pt][j];
+  });
+  bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                          [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+  // phi; xi_prev seeded: g = -(dC/dxi_prev)^T phi (:636-642); x_prev seeded through q_prev: w = (dC/dq_prev)^T phi
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const pt = lane >> 3, d = lane & 7;
+    size_t const qp = (size_t)e * E::NP0 + pt;
+    if (d == 0) {
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) aa.phi[qp * NL + j] = r.b[j];
+      if (!ok) sh.failed = 1;
+    }
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) { r.m.xi[j].d = 0.; r.m.xi_prev[j].d = (j == d) ? 1. : 0.; }
+    r.m.evaluate(r.g, ms.abs_tol);
+    double gk = 0.;
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) gk -= r.m.R[j].d * r.b[j];
+    if (d < NL) aa.g[qp * NL + d] = gk;
+    if (PREV) {
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) r.m.xi_prev[j].d = 0.;
+      C8_UNROLL
+      for (int round = 0; round < 2; ++round) {
+        int const c = (round == 0) ? d : 8;
+        Tens3<Dual>& G = r.g.grad_u_prev;
+        G.xx.d = (c == 0) ? 1. : 0.; G.xy.d = (c == 1) ? 1. : 0.; G.xz.d = (c == 2) ? 1. : 0.;
+        G.yx.d = (c == 3) ? 1. : 0.; G.yy.d = (c == 4) ? 1. : 0.; G.yz.d = (c == 5) ? 1. : 0.;
+        G.zx.d = (c == 6) ? 1. : 0.; G.zy.d = (c == 7) ? 1. : 0.; G.zz.d = (c == 8) ? 1. : 0.;
+        r.m.evaluate(r.g, ms.abs_tol);
+        double wc = 0.;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) wc += r.m.R[j].d * r.b[j];
+        if (round == 0 || d == 0) sh.wq[pt][c] = wc;
+      }
+    }
+  });
+  ex.sync();
+  // f = -(dC/dx_prev)^T phi = -B_prev^T w  (:628-633): 8 points x 32 element DOFs, 4 per lane
+  ex.each([&](int lane) {
+    C8_UNROLL
+    for (int t = 0; t < 4; ++t) {
+      int const idx = t * 64 + lane, pt = idx >> 5, b = idx & 31;
+      double fv = 0.;
+      if (PREV && b < 3 * E::NN) {
+        int const m = b / 3, k = b - 3 * m;
+        fv = -(sh.wq[pt][3 * k] * sh.dN[pt][m][0] + sh.wq[pt][3 * k + 1] * sh.dN[pt][m][1] + sh.wq[pt][3 * k + 2] * sh.dN[pt][m][2]);
+      }
+      aa.f[(size_t)e * E::NP0 * E::NDOF + idx] = fv;
+    }
+    if (lane == 0 && sh.failed) ex.flag(sa.status);
+  });
+}
+
+// K5: eval_qoi_gradient (evaluations.cpp:758-925); lane (point, d) carries d/d(param active[d])
+template <class E, template <class> class ModelT, class QoI, class EX>
+C8_HD void param_gradient_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, ModelSettings const& ms,
+                               FieldArgs const& fa, AdjointArgs const& aa, int e) {
+  using Model = ModelT<Dual>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  static_assert(E::NDOF == 32 && E::NP0 == 8 && E::SAME_POINTS, "wave kernel needs a hex8-like element");
+  wave_prologue<E, NL, PREV>(ex, sh, mt, fa, aa, e);
+  int const es = mt.elem_set ? mt.elem_set[e] : 0;
+  int32_t const* act = aa.active + es * 10;
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    int const pt = lane >> 3, d = lane & 7;
+    size_t const qp = (size_t)e * E::NP0 + pt;
+    int const nact = act[1];
+    int const mine = (d < nact) ? act[2 + d] : -1;
+    int const slot = (d < nact) ? act[0] + d : -1;
+    if (slot != r.slot) {  // the group moved to another element set: flush the previous sum
+      if (r.slot >= 0) ex.add(aa.out + r.slot, r.acc, 1);
+      r.acc = 0.;
+      r.slot = slot;
+    }
+    if (slot < 0) return;
+    C8_UNROLL
+    for (int q = 0; q < Model::NPARAMS; ++q)
+      r.m.params[q] = Dual(mt.params[es * Model::NPARAMS + q], (q == mine) ? 1. : 0.);
+    load_point(sh, pt, r.g, PREV);
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) {
+      r.m.xi_prev[j] = Dual(sh.xip[pt][j]);
+      r.m.xi[j] = Dual(sh.xi[pt][j]);
+      r.m.R[j] = Dual(0.);
+    }
+    r.m.evaluate(r.g, ms.abs_tol);
+    double s = 0.;
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];   // (dC/dp)^T phi
+    s += QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;                          // dJ/dp
+    MechFlux<Dual> f;
+    Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+    f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);                    // both ip sets (same points)
+    s += flux_dot_zq(sh, pt, f);                                         // (dR/dp)^T z
+    r.acc += s;
+  });
+  ex.sync();
+}
+
+template <class EX> C8_HD void param_gradient_wave_flush(EX& ex, AdjointArgs const& aa) {
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    if (r.slot >= 0) ex.add(aa.out + r.slot, r.acc, 1);
+    r.slot = -1;
+    r.acc = 0.;
+  });
+}
+
 }  // namespace c8

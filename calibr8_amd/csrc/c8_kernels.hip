@@ -135,6 +135,55 @@ static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
   return hipGetLastError();
 }
 
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK, 2) k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+                                                               SystemArgs sa, int first, int count, int nblocks) {
+  constexpr int WPB = BLOCK / 64;
+  using Lane = WaveLaneA<ModelT>;
+  __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int const gi = lb * WPB + wib;
+  if (gi >= count) return;
+  Lane L;
+  GpuExec<Lane> ex(lane, L);
+  adjoint_local_wave<E, ModelT>(ex, shs[wib], mt, ms, fa, aa, sa, first + gi);
+}
+
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK, 2) k_param_gradient_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
+  constexpr int WPB = BLOCK / 64;
+  using Lane = WaveLaneA<ModelT>;
+  __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Lane L;
+  L.slot = -1;
+  L.acc = 0.;
+  GpuExec<Lane> ex(lane, L);
+  for (int e = blockIdx.x * WPB + wib; e < count; e += gridDim.x * WPB)
+    param_gradient_wave<E, ModelT, AvgDisp>(ex, shs[wib], mt, ms, fa, aa, e);
+  param_gradient_wave_flush(ex, aa);
+}
+
+template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local_wave(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  int const nblocks = (a.count + WPB - 1) / WPB;
+  int const grid = ((nblocks + 7) / 8) * 8;
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_adjoint_local_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.sa,
+                     a.first, a.count, nblocks);
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT> static hipError_t launch_param_gradient_wave(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  int const nblocks = (a.count + WPB - 1) / WPB;
+  if (a.count <= 0) return hipSuccess;
+  int const grid = nblocks < 4096 ? nblocks : 4096;
+  hipLaunchKernelGGL((k_param_gradient_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.count);
+  return hipGetLastError();
+}
+
 // group index -> element for the colour-batched / atomic element-parallel kernels
 #define C8_GROUP_PROLOGUE(E)                                                  \
   constexpr int GPB = BLOCK / E::NDOF;                                        \
@@ -255,10 +304,14 @@ template <class E, template <class> class ModelT> static hipError_t launch_qoi(L
 template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get() { return nullptr; }
   static LaunchFn get_adjoint() { return nullptr; }
+  static LaunchFn get_adjoint_local() { return nullptr; }
+  static LaunchFn get_param_gradient() { return nullptr; }
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint() { return &launch_adjoint_jacobian_wave<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_adjoint_local() { return &launch_adjoint_local_wave<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_param_gradient() { return &launch_param_gradient_wave<Elem<C8_HEX8>, ModelT>; }
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
@@ -266,6 +319,8 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.forward_jacobian = &launch_forward<E, ModelT>;
   ks.forward_jacobian_wave = WaveKernel<E, ModelT>::get();
   ks.adjoint_jacobian_wave = WaveKernel<E, ModelT>::get_adjoint();
+  ks.adjoint_local_wave = WaveKernel<E, ModelT>::get_adjoint_local();
+  ks.param_gradient_wave = WaveKernel<E, ModelT>::get_param_gradient();
   ks.residual = &launch_residual<E, ModelT>;
   ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;

@@ -29,6 +29,8 @@ struct KernelSet {
   LaunchFn adjoint_jacobian_wave;  // K3, one wavefront per element (hex8 only, else null)
   LaunchFn adjoint_local;      // K4 (per-point outputs only: one launch, no colouring)
   LaunchFn param_gradient;     // K5 (grid-stride, one atomic per lane at the end)
+  LaunchFn adjoint_local_wave;     // K4, one wavefront per element (hex8 only, else null)
+  LaunchFn param_gradient_wave;    // K5, one wavefront per element (hex8 only, else null)
   LaunchFn qoi;                // K6
 };
 

@@ -27,7 +27,7 @@ template <class Lane, int NDOF> struct CpuExec {
   void flag(int* s) { *s = 1; }
 };
 
-enum { K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 struct Call {
   int what;
@@ -73,6 +73,20 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
   }
 }
 
+template <template <class> class ModelT> static void run_wave_adjoint(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  auto* sh = new WaveSharedA<E, ModelT<Dual>::NLOC>();
+  auto* ex = new CpuExec<WaveLaneA<ModelT>, 64>();
+  for (int k = 0; k < 64; ++k) { ex->lanes[k].slot = -1; ex->lanes[k].acc = 0.; }
+  for (int e = 0; e < c.nelems; ++e) {
+    if (c.what == K_ADJ_LOCAL_WAVE) adjoint_local_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+    else param_gradient_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e);
+  }
+  if (c.what == K_GRAD_WAVE) param_gradient_wave_flush(*ex, c.aa);
+  delete ex;
+  delete sh;
+}
+
 template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
@@ -86,6 +100,14 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
 }
 
 template <class E> static int dispatch(std::string const& model, Call const& c) {
+  if (c.what == K_ADJ_LOCAL_WAVE || c.what == K_GRAD_WAVE) {
+    if (E::TYPE != C8_HEX8) return -4;
+    if (model == "elastic") run_wave_adjoint<Elastic>(c);
+    else if (model == "small_J2") run_wave_adjoint<SmallJ2>(c);
+    else if (model == "hyper_J2") run_wave_adjoint<HyperJ2>(c);
+    else return -2;
+    return 0;
+  }
   if (c.what == K_FORWARD_WAVE || c.what == K_ADJ_JAC_WAVE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "elastic") run_wave<Elastic>(c);

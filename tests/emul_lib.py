@@ -15,7 +15,7 @@ EMUL_DIR = os.path.join(HERE, "emul")
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
-K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE = 1, 2, 3, 4, 5, 6, 7, 8
+K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 def lib():
@@ -94,12 +94,12 @@ class Emul:
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls), 12: g, 13: f})
 
     def solve_adjoint_local(self, u, p, up, pp, xip, xi, z_u, z_p, phi, g, f):
-        return self._call(K_ADJ_LOCAL, {**self._fields(u, p, up, pp, xip, xi), 12: g, 13: f, 14: z_u, 15: z_p,
+        return self._call(K_ADJ_LOCAL_WAVE if self.wave else K_ADJ_LOCAL, {**self._fields(u, p, up, pp, xip, xi), 12: g, 13: f, 14: z_u, 15: z_p,
                                         16: phi})
 
     def qoi_gradient(self, u, p, up, pp, xip, xi, z_u, z_p, phi, nparams):
         grad = np.zeros(nparams)
-        self._call(K_GRAD, {**self._fields(u, p, up, pp, xip, xi), 14: z_u, 15: z_p, 16: phi, 17: grad})
+        self._call(K_GRAD_WAVE if self.wave else K_GRAD, {**self._fields(u, p, up, pp, xip, xi), 14: z_u, 15: z_p, 16: phi, 17: grad})
         return grad
 
     def eval_qoi(self, u, p):

@@ -58,10 +58,12 @@ def main():
     for k in ("wave", "slot"):
         asm.set_kernel(k)
         res["adjoint_jacobian_" + k] = timeit(lambda: asm.adjoint_jacobian(u, p, u0, p0, xi0, xi, g, f, ls))
+    for k in ("wave", "slot"):
+        asm.set_kernel(k)
+        res["solve_adjoint_local_" + k] = timeit(lambda: asm.solve_adjoint_local(u, p, u0, p0, xi0, xi, z_u, z_p, phi, g, f))
+        res["param_gradient_" + k] = timeit(lambda: asm.qoi_gradient(u, p, u0, p0, xi0, xi, z_u, z_p, phi, grad))
     asm.set_kernel("auto")
     res["residual"] = timeit(lambda: asm.global_residual(u, p, u0, p0, xi0, xi, ls))
-    res["solve_adjoint_local"] = timeit(lambda: asm.solve_adjoint_local(u, p, u0, p0, xi0, xi, z_u, z_p, phi, g, f))
-    res["param_gradient"] = timeit(lambda: asm.qoi_gradient(u, p, u0, p0, xi0, xi, z_u, z_p, phi, grad))
     res["eval_qoi"] = timeit(lambda: asm.eval_qoi(u, p, J))
     out = {"elements": asm.nelems, "scatter": args.scatter,
            "ms": res, "Melem_per_s": {k: asm.nelems / v / 1e3 for k, v in res.items()}}
