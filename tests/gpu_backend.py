@@ -20,7 +20,8 @@ class HostLinSys:
 class GpuBackend:
     def __init__(self, elem_type, coords, conn, local_type, params, scatter="colored", kernel="auto", **kw):
         self.asm = Assembler(elem_type, coords, conn, local_type, params, scatter=scatter, **kw)
-        self.asm.set_kernel(kernel)
+        if not (kernel == "wave" and elem_type != 8):
+            self.asm.set_kernel(kernel)
         a = self.asm
         self.nnodes, self.nelems, self.nn = a.nnodes, a.nelems, a.nn
         self.npts, self.nloc = a.npts, a.nloc

@@ -107,3 +107,55 @@ def check_adjoint_chain(orc, dut, c, model, eps, tol):
         assert (np.abs(gr_d - gr_o) / scale).max() < 1e-11, ("qoi_gradient", n, gr_d, gr_o)
         # K6
         assert abs(dut.eval_qoi(u, p) - orc.eval_qoi(u, p)) < tol * max(1.0, abs(orc.eval_qoi(u, p)))
+
+
+def check_two_element_sets(factory, kind, tol, wave=None):
+    """Two material blocks with different parameters and different active-parameter lists
+    (local_residual.cpp:96-100 per-set parameters, :812-819 seed_wrt_params(es), :859-867 scatter_es_gradient)."""
+    et, c, conn = mesh_of(kind)
+    nelems = len(conn)
+    rng = np.random.default_rng(21)
+    es = (rng.random(nelems) < 0.4).astype(np.int32)  # ragged: sets are interleaved, not contiguous
+    params = [[1000.0, 0.25, 100.0, 2.0, 0.0, 0.0], [700.0, 0.3, 50.0, 1.2, 1e-4, 5.0]]
+    orc = ol.Oracle(et, c, conn, "small_J2", params, elem_set=es)
+    dut = factory(et, c, conn, "small_J2", params, elem_set=es)
+    if wave is not None:
+        dut.wave = wave
+    st = two_steps(orc, c, 0.004)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    ls_o, ls_d, xo, xd = orc.new_linsys(), dut.new_linsys(), orc.new_state(), dut.new_state()
+    assert orc.forward_jacobian(u, p, up, pp, xip, xo, ls_o) == 0
+    assert dut.forward_jacobian(u, p, up, pp, xip, xd, ls_d) == 0
+    errs = compare_systems(orc, ls_d, ls_o)
+    errs["xi"] = rel_vec(xd, xo)
+    assert max(errs.values()) < tol, errs
+    for b, a0, a1 in ((orc, [0, 3], [1, 2, 3]), (dut, [0, 3], [1, 2, 3])):
+        b.set_active(0, a0)
+        b.set_active(1, a1)
+    nd = 4 * orc.nn
+    g = np.zeros((orc.nelems, orc.npts, orc.nloc))
+    f = np.zeros((orc.nelems, orc.npts, nd))
+    orc.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, orc.new_linsys())
+    z_u, z_p = rng.standard_normal(len(u)) * 1e-3, rng.standard_normal(len(p)) * 1e-3
+    phi = np.zeros_like(g)
+    orc.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
+    gr_o = orc.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
+    gr_d = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
+    assert np.abs(gr_o).min() > 0 and (np.abs(gr_d - gr_o) / np.abs(gr_o)).max() < 1e-11, (gr_d, gr_o)
+
+
+def check_tiny_and_ragged(factory, tol):
+    """One element, and element counts that do not fill a workgroup / wavefront."""
+    for n in ((1, 1, 1), (3, 1, 1), (5, 1, 1), (3, 3, 1)):
+        c, conn, sets = brick(n[0], n[1], n[2], 1.0 * n[0], 1.0 * n[1], 1.0 * n[2])
+        orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+        dut = factory(ol.HEX8, c, conn, "small_J2", J2)
+        check_forward(orc, dut, c, "small_J2", 0.0035, tol)
+    c = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]])
+    conn = np.array([[0, 1, 2, 3], [1, 2, 3, 4]], dtype=np.int32)  # two tets; second one re-oriented below
+    v = np.linalg.det(c[conn[1]][1:] - c[conn[1]][0])
+    if v < 0:
+        conn[1] = conn[1][[0, 2, 1, 3]]
+    orc = ol.Oracle(ol.TET4, c, conn, "hyper_J2", HJ2)
+    dut = factory(ol.TET4, c, conn, "hyper_J2", HJ2)
+    check_forward(orc, dut, c, "hyper_J2", 0.004, tol)

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import emul_lib as em
-from parity_cases import CASES, MESHES, check_adjoint_chain, check_forward, check_residual, make_pair
+from parity_cases import (CASES, MESHES, check_adjoint_chain, check_forward, check_residual, check_tiny_and_ragged,
+                          check_two_element_sets, make_pair)
 
 TOL = 1e-12
 
@@ -49,3 +50,12 @@ def test_adjoint_chain_wave_kernel(model, params, eps):
     orc, dut, c = make_pair(factory, "hex8", model, params)
     dut.wave = True
     check_adjoint_chain(orc, dut, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("kind,wave", [("hex8", False), ("hex8", True), ("tet4", False)])
+def test_two_element_sets(kind, wave):
+    check_two_element_sets(factory, kind, TOL, wave=wave)
+
+
+def test_tiny_and_ragged_meshes():
+    check_tiny_and_ragged(factory, TOL)

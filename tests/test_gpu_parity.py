@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-12
 
 
-from parity_cases import CASES, MESHES, check_adjoint_chain, check_forward, check_residual, make_pair
+from parity_cases import (CASES, MESHES, check_adjoint_chain, check_forward, check_residual, check_tiny_and_ragged,
+                          check_two_element_sets, make_pair)
 
 
 def hex_mesh(n=(6, 5, 4)):
@@ -112,6 +113,17 @@ def test_adjoint_gradient_fd_check_through_gpu():
         errs.append(abs((objective(pp)[0] - objective(pm)[0]) / (2 * h) - gd))
     errs = np.array(errs)
     assert np.log10(errs.max() / errs.min()) > 5.0 and errs.min() < 1e-6 * abs(gd), (errs, gd)
+
+
+@pytest.mark.parametrize("kind,kernel", [("hex8", "wave"), ("hex8", "slot"), ("tet4", "auto")])
+@pytest.mark.parametrize("scatter", ["colored", "atomic"])
+def test_two_element_sets(kind, kernel, scatter):
+    check_two_element_sets(factory(scatter, kernel), kind, TOL)
+
+
+@pytest.mark.parametrize("kernel", ["wave", "slot"])
+def test_tiny_and_ragged_meshes(kernel):
+    check_tiny_and_ragged(factory("colored", kernel), TOL)
 
 
 def test_forward_jacobian_accumulates_into_outputs():
