@@ -306,4 +306,64 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
   return C8_OK;
 }
 
+int c8_adjoint_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs,
+                          c8_linear_solve_fn solve, void* user, double* const z[2], double* phi, double* g, double* f,
+                          double* grad) {
+  if (!c || !st || !sys || !solve || !z || !z[0] || !z[1] || !phi || !g || !f || !grad)
+    return c8_fail(C8_ERR_ARG, "c8_adjoint_solve_step: null argument");
+  size_t const n[2] = {(size_t)c->mesh.nnodes * 3, (size_t)c->mesh.nnodes};
+  for (int i = 0; i < 2; ++i) {  // la->zero_all (adjoint.cpp:118)
+    C8P_HIP(hipMemsetAsync(sys->b[i], 0, n[i] * sizeof(double), c->stream));
+    for (int j = 0; j < 2; ++j)
+      C8P_HIP(hipMemsetAsync(sys->A[i][j], 0, (size_t)c->graph.nodeptr[c->mesh.nnodes] * neq_of(i) * neq_of(j) * sizeof(double), c->stream));
+  }
+  int const saved_async = c->async;
+  c->async = 0;
+  int rc = c8_assemble_adjoint_jacobian(c, st, g, f, sys);
+  if (rc == C8_OK) {
+    const double* zc[2] = {z[0], z[1]};
+    rc = c8_apply_dirichlet(c, ndbc, dbcs, zc, sys, 1);  // apply_primal_dbcs(..., is_adjoint) (adjoint.cpp:137)
+  }
+  if (rc == C8_OK) {
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = c8_fail(C8_ERR_DEVICE, "c8_adjoint_solve_step: sync failed");
+    else if (solve(user, sys, z) != 0) rc = c8_fail(C8_ERR_ARG, "c8_adjoint_solve_step: linear solve callback failed");
+  }
+  const double* zc[2] = {z[0], z[1]};
+  if (rc == C8_OK) rc = c8_solve_adjoint_local(c, st, zc, phi, g, f);       // adjoint.cpp:182
+  if (rc == C8_OK) rc = c8_param_gradient(c, st, zc, phi, grad);            // adjoint_objective.cpp:90-93
+  c->async = saved_async;
+  return rc;
+}
+
+int c8_transform_params(int n, const double* values, const int32_t* kind, const double* a, const double* b,
+                        int from_canonical, double* out) {
+  if (n < 0 || !values || !kind || !a || !b || !out) return c8_fail(C8_ERR_ARG, "c8_transform_params: null argument");
+  for (int i = 0; i < n; ++i) {
+    double const v = values[i];
+    if (kind[i] == C8_SCALE_NONE) out[i] = v;
+    else if (kind[i] == C8_SCALE_LOG) out[i] = from_canonical ? a[i] * std::exp(v) : std::log(v / a[i]);
+    else if (kind[i] == C8_SCALE_BOUNDS) {
+      double const span = 0.5 * (b[i] - a[i]), mean = 0.5 * (a[i] + b[i]);
+      if (from_canonical) out[i] = span * v + mean;
+      else {
+        double const cl = v < a[i] ? a[i] : (v > b[i] ? b[i] : v);
+        out[i] = (cl - mean) / span;
+      }
+    } else return c8_fail(C8_ERR_ARG, "c8_transform_params: unknown scale kind");
+  }
+  return C8_OK;
+}
+
+int c8_transform_gradient(int n, const double* grad, const double* values, const int32_t* kind, const double* a,
+                          const double* b, double* out) {
+  if (n < 0 || !grad || !values || !kind || !a || !b || !out) return c8_fail(C8_ERR_ARG, "c8_transform_gradient: null argument");
+  for (int i = 0; i < n; ++i) {
+    if (kind[i] == C8_SCALE_NONE) out[i] = grad[i];
+    else if (kind[i] == C8_SCALE_LOG) out[i] = grad[i] * values[i];
+    else if (kind[i] == C8_SCALE_BOUNDS) out[i] = grad[i] * 0.5 * (b[i] - a[i]);
+    else return c8_fail(C8_ERR_ARG, "c8_transform_gradient: unknown scale kind");
+  }
+  return C8_OK;
+}
+
 }  // extern "C"

@@ -9,6 +9,7 @@ C8_ELEM_TET4, C8_ELEM_HEX8 = 4, 8
 C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED, C8_NOT_CONVERGED = 0, -1, -2, -3, -4, -5
 C8_SCATTER_ATOMIC, C8_SCATTER_COLORED = 0, 1
 C8_KERNEL_AUTO, C8_KERNEL_SLOT, C8_KERNEL_WAVE = 0, 1, 2
+C8_SCALE_NONE, C8_SCALE_LOG, C8_SCALE_BOUNDS = 0, 1, 2
 
 dp = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)
@@ -89,6 +90,10 @@ SYMBOLS = [
     ("c8_apply_A", C.c_int, [C.c_void_p, C.POINTER(System), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("c8_primal_solve_step", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System), C.c_int, C.POINTER(Dbc), C.c_int,
                                        C.POINTER(Tbc), C.POINTER(NewtonOpts), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    ("c8_adjoint_solve_step", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System), C.c_int, C.POINTER(Dbc), C.c_void_p,
+                                        C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("c8_transform_params", C.c_int, [C.c_int, dp, i32p, dp, dp, C.c_int, dp]),
+    ("c8_transform_gradient", C.c_int, [C.c_int, dp, dp, i32p, dp, dp, dp]),
     ("c8_brick_mesh", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, i32p]),
     ("c8_brick_partition", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
 ]

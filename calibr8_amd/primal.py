@@ -143,3 +143,33 @@ class PrimalDriver:
             self.asm.eval_qoi(self.u[s], self.p[s], J)
         self.torch.cuda.synchronize()
         return float(J.item())
+
+
+def adjoint_gradient(primal, nparams):
+    """Adjoint_Objective::gradient (adjoint_objective.cpp:83-109) for one part on the device: march the load
+    steps backwards through c8_adjoint_solve_step and return dJ/dp (host array, physical parameters).
+    `primal` is a solved PrimalDriver; the active parameters are those set with Assembler.set_active."""
+    torch, asm = primal.torch, primal.asm
+    dev = asm.device
+    nsteps = len(primal.u) - 1
+    g = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=dev)
+    f = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=dev)
+    phi = torch.zeros_like(g)
+    grad = torch.zeros(nparams, dtype=torch.float64, device=dev)
+    z_u = torch.zeros(asm.nnodes * 3, dtype=torch.float64, device=dev)
+    z_p = torch.zeros(asm.nnodes, dtype=torch.float64, device=dev)
+    sy = primal.ls.c_struct()
+    zero_vals = [asm.dev(np.zeros(len(nodes))) for _, _, nodes, _ in primal.dbcs]
+    d = (_l.Dbc * max(1, len(primal.dbcs)))()
+    for k, (resid, eq, nodes, _) in enumerate(primal.dbcs):
+        d[k] = _l.Dbc(resid, eq, len(nodes), primal._dbc_nodes[k].data_ptr(), zero_vals[k].data_ptr())
+    for step in range(nsteps, 0, -1):
+        st = asm._state(primal.u[step], primal.p[step], primal.u[step - 1], primal.p[step - 1], primal.xi[step - 1],
+                        primal.xi[step])
+        z = (C.c_void_p * 2)(z_u.data_ptr(), z_p.data_ptr())
+        rc = asm.L.c8_adjoint_solve_step(asm.h, C.byref(st), C.byref(sy), len(primal.dbcs), d,
+                                         C.cast(primal.solver, C.c_void_p), None, z, C.c_void_p(phi.data_ptr()),
+                                         C.c_void_p(g.data_ptr()), C.c_void_p(f.data_ptr()), C.c_void_p(grad.data_ptr()))
+        _l.check(rc)
+    torch.cuda.synchronize()
+    return grad.cpu().numpy()

@@ -186,6 +186,28 @@ int c8_primal_solve_step(c8_ctx* ctx, const c8_state* st, const c8_system* sys, 
                          const c8_tbc* tbcs, const c8_newton_opts* opts, c8_linear_solve_fn solve, void* user,
                          int32_t* iters);
 
+/* Adjoint::solve_at_step (adjoint.cpp:76-189) followed by eval_qoi_gradient (adjoint_objective.cpp:86-94)
+ * for one load step of one part: zero + c8_assemble_adjoint_jacobian, adjoint Dirichlet rows, the
+ * caller's linear solve (system passed as assembled: A = (dR/dx)^T, b = right-hand side, NOT negated;
+ * the solution is written to z), c8_solve_adjoint_local, and grad += this step's contribution.
+ * March the steps from the last to the first with the same g, f arrays (zero before the last step). */
+int c8_adjoint_solve_step(c8_ctx* ctx, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs,
+                          c8_linear_solve_fn solve, void* user, double* const z[2], double* phi, double* g, double* f,
+                          double* grad);
+
+/* ---- canonical optimisation variables (HOST arrays) -------------------------------
+ * Objective::transform_params / transform_gradient (objective.cpp:41-61,125-137) and their Python twins
+ * (python/calibr8/util/parameter_transforms.py:31-59).  kind[i]: C8_SCALE_NONE (identity),
+ * C8_SCALE_LOG (a = reference value: canonical = log(value / a)), C8_SCALE_BOUNDS (a = lower, b = upper:
+ * canonical = (clip(value) - mean) / span in [-1, 1]). */
+enum { C8_SCALE_NONE = 0, C8_SCALE_LOG = 1, C8_SCALE_BOUNDS = 2 };
+int c8_transform_params(int n, const double* values, const int32_t* kind, const double* a, const double* b,
+                        int from_canonical, double* out);
+/* d(objective)/d(canonical) from d(objective)/d(physical); `values` are the CANONICAL values for log
+ * scales, as in grad_transform (parameter_transforms.py:53-59). */
+int c8_transform_gradient(int n, const double* grad, const double* values, const int32_t* kind, const double* a,
+                          const double* b, double* out);
+
 /* ---- host helpers for synthetic problems -------------------------------- */
 /* Structured hex8 brick; coords [(nx+1)(ny+1)(nz+1)][3], conn [nx*ny*nz][8] (host arrays). */
 int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, double* coords, int32_t* conn);
