@@ -82,6 +82,10 @@ template <class E, int NL> struct GroupShared {
   double dN[NPT][E::NN][3];
   double wdv[NPT];
   double M[NL][NL + 1];
+  // adjoint assembly of small elements: element matrix transposed through LDS before the scatter, so
+  // that the lanes of one scatter instruction share a CSR row (hex8 uses the wave kernel instead)
+  static constexpr int NJT = (E::NDOF <= 16) ? E::NDOF : 1;
+  double JT[NJT][NJT + 1];
   double vec[NL + 1];      // right-hand side / history exchange between lanes
   double z[E::NDOF];       // element adjoint solution (gather_adjoint, global_residual.cpp:423-438)
   double h;

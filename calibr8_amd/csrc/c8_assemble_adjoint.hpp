@@ -234,7 +234,26 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
     }
   }
   ex.sync();
-  scatter_lhs<E>(ex, sh, mt, sa, e, true, [&](int k) { return ex.lane(k).Jcol; });
+  if (E::NDOF <= 16) {
+    // lane k holds column k of dtotal; the assembled matrix is dtotal^T.  Scattering column k as row k
+    // would send the 16 lanes of an instruction to 16 different CSR rows (measured 2-3x slower), so
+    // transpose through LDS: afterwards lane k holds row k of dtotal = column k of dtotal^T.
+    constexpr int NJ = (E::NDOF <= 16) ? E::NDOF : 1;
+    ex.each([&](int k) {
+      auto& r = ex.lane(k);
+      C8_UNROLL
+      for (int a = 0; a < NJ; ++a) sh.JT[k % NJ][a] = r.Jcol[a];
+    });
+    ex.sync();
+    ex.each([&](int k) {
+      auto& r = ex.lane(k);
+      C8_UNROLL
+      for (int a = 0; a < NJ; ++a) r.Jcol[a] = sh.JT[a][k % NJ];
+    });
+    scatter_lhs<E>(ex, sh, mt, sa, e, false, [&](int k) { return ex.lane(k).Jcol; });
+  } else {
+    scatter_lhs<E>(ex, sh, mt, sa, e, true, [&](int k) { return ex.lane(k).Jcol; });
+  }
   scatter_rhs<E>(ex, sh, sa, [&](int k) { return ex.lane(k).rhs; });
   ex.each([&](int k) {
     if (k == 0 && ex.lane(k).failed) ex.flag(sa.status);

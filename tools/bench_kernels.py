@@ -18,13 +18,23 @@ def main():
     ap.add_argument("--edge", type=int, default=100)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--scatter", default="atomic")
+    ap.add_argument("--tet", action="store_true", help="split every hex into 6 tet4 (the reference's element type)")
     args = ap.parse_args()
     import torch
     from calibr8_amd import Assembler, brick_mesh
     from meshes import prescribed_fields
     n = args.edge
     coords, conn = brick_mesh(n, n, n)
-    asm = Assembler(8, coords, conn, "small_J2", J2, scatter=args.scatter)
+    et = 8
+    if args.tet:
+        # Kuhn split of each hex into 6 positively oriented tets sharing the 0-6 diagonal
+        tets = [[0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6], [0, 5, 1, 6]]
+        conn = np.concatenate([conn[:, t] for t in tets]).astype(np.int32)
+        X = coords[conn]
+        vol = np.einsum("ij,ij->i", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0])
+        assert (vol > 0).all()
+        et = 4
+    asm = Assembler(et, coords, conn, "small_J2", J2, scatter=args.scatter)
     asm.set_active(0, [0, 1, 2, 3])
     asm.set_async(True)
     u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
@@ -52,20 +62,21 @@ def main():
         return a.elapsed_time(b) / args.reps
 
     res = {}
-    for k in ("wave", "slot"):
+    variants = ("slot",) if args.tet else ("wave", "slot")
+    for k in variants:
         asm.set_kernel(k)
         res["forward_jacobian_" + k] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))
-    for k in ("wave", "slot"):
+    for k in variants:
         asm.set_kernel(k)
         res["adjoint_jacobian_" + k] = timeit(lambda: asm.adjoint_jacobian(u, p, u0, p0, xi0, xi, g, f, ls))
-    for k in ("wave", "slot"):
+    for k in variants:
         asm.set_kernel(k)
         res["solve_adjoint_local_" + k] = timeit(lambda: asm.solve_adjoint_local(u, p, u0, p0, xi0, xi, z_u, z_p, phi, g, f))
         res["param_gradient_" + k] = timeit(lambda: asm.qoi_gradient(u, p, u0, p0, xi0, xi, z_u, z_p, phi, grad))
     asm.set_kernel("auto")
     res["residual"] = timeit(lambda: asm.global_residual(u, p, u0, p0, xi0, xi, ls))
     res["eval_qoi"] = timeit(lambda: asm.eval_qoi(u, p, J))
-    out = {"elements": asm.nelems, "scatter": args.scatter,
+    out = {"elements": asm.nelems, "element_type": "tet4" if args.tet else "hex8", "scatter": args.scatter,
            "ms": res, "Melem_per_s": {k: asm.nelems / v / 1e3 for k, v in res.items()}}
     print(json.dumps(out))
 
