@@ -411,20 +411,23 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       int const k = bu ? b - 3 * m : 0;
       int const cg = bu ? 3 * k : 10;       // first gradient column of D that x_b drives
       int const cv = bu ? 13 + k : 9;       // value column of D that x_b drives
-      bool const has_cv = Mechanics::USES_U || !bu;  // the weak form does not read u itself
+      // the weak form does not read u itself: the u-value column is multiplied by zero instead of being
+      // skipped under a lane-dependent branch (a branch per row serialises the LDS reads of this loop)
+      bool const has_cv = Mechanics::USES_U || !bu;
+      int const cvl = has_cv ? cv : 9;
       C8_NOUNROLL
       for (int ql = 0; ql < 4; ++ql) {
         int const pt = 4 * t + ql;
         double const w = sh.wdv[pt];
         double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
+        double const bNv = has_cv ? bN : 0.;
+        double const bNp = bu ? 0. : bN;
         if (!ADJOINT) {
           double T[WF];  // T[r] = w * sum_c D[r][c] dq_c/dx_b
           C8_UNROLL
           for (int rr = 0; rr < WF; ++rr) {
             double const* Dr = sh.D[ql][rr];
-            double tt = Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2;
-            if (has_cv) tt += Dr[cv] * bN;
-            T[rr] = w * tt;
+            T[rr] = w * (Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cvl] * bNv);
           }
           C8_UNROLL
           for (int nl = 0; nl < 4; ++nl) {
@@ -441,9 +444,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
           double U[WQ];  // U[c] = w * sum_r dR_a/dflux_r D[r][c]
           C8_UNROLL
           for (int c = 0; c < WQ; ++c) {
-            double tt = sh.D[ql][cg][c] * b0 + sh.D[ql][cg + 1][c] * b1 + sh.D[ql][cg + 2][c] * b2;
-            if (!bu) tt += sh.D[ql][9][c] * bN;
-            U[c] = w * tt;
+            U[c] = w * (sh.D[ql][cg][c] * b0 + sh.D[ql][cg + 1][c] * b1 + sh.D[ql][cg + 2][c] * b2 + sh.D[ql][9][c] * bNp);
           }
           C8_UNROLL
           for (int nl = 0; nl < 4; ++nl) {
@@ -455,13 +456,10 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
             r.J[4 * nl + 3] += aN * U[9] + a0 * U[10] + a1 * U[11] + a2 * U[12];
           }
         }
-        if (half == 0 && !ADJOINT) {  // residual entry b from the flux values
+        if (!ADJOINT) {  // residual entry b from the flux values (both halves compute it, half 0 stores it)
           double const* Fp = sh.F[pt];
-          int const fr = bu ? 3 * k : 10;
-          double const rv = Fp[fr] * b0 + Fp[fr + 1] * b1 + Fp[fr + 2] * b2 + (bu ? 0. : Fp[9] * bN);
-          r.R += w * rv;
-        }
-        if (half == 0 && ADJOINT) {  // rhs_b = sum_c [-dJ/dq_c + (dxi/dq_c).g] dq_c/dx_b + f_b  (:486-487)
+          r.R += w * (Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * bNp);
+        } else {  // rhs_b = sum_c [-dJ/dq_c + (dxi/dq_c).g] dq_c/dx_b + f_b  (:486-487)
           double const* rq = sh.rq[ql];
           r.R += rq[cg] * b0 + rq[cg + 1] * b1 + rq[cg + 2] * b2 + rq[cv] * bN +
                  aa.f[((size_t)e * E::NP0 + pt) * E::NDOF + b];
@@ -480,18 +478,25 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     slot_to_dof<E>(b, ib, nb, eqb);
     int const neqb = ib == 0 ? 3 : 1;
     uint8_t const* posb = mt.pos + ((size_t)e * E::NN + nb) * E::NN;  // pos[e][col node nb][row node]
-    C8_UNROLL
-    for (int nl = 0; nl < 4; ++nl) {
-      int const n = 4 * half + nl;
-      // forward: J[(n,i)][b]; adjoint: the lane already holds the transposed entries J[b][(n,i)], so in
-      // both cases this is assembled entry (row (n,i), column b) and the lanes of one instruction share rows
-      size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
+    // forward: J[(n,i)][b]; adjoint: the lane already holds the transposed entries J[b][(n,i)], so in both
+    // cases this is assembled entry (row (n,i), column b) and the lanes of one instruction share rows.
+    // One uniform branch selects atomic or plain adds for the whole batch (a branch per add would keep the
+    // adds from being issued back to back).
+    auto scatter_all = [&](auto mode) {
+      constexpr int ATOMIC = decltype(mode)::value;
       C8_UNROLL
-      for (int i = 0; i < 3; ++i)  // u rows of node n: block (0, ib)
-        ex.add(sa.A[0][ib] + nptr * (3 * neqb) + (size_t)i * deg * neqb + pos * neqb + eqb, r.J[4 * nl + i], sa.atomic);
-      ex.add(sa.A[1][ib] + nptr * neqb + pos * neqb + eqb, r.J[4 * nl + 3], sa.atomic);  // p row: block (1, ib)
-    }
-    if (half == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, sa.atomic);
+      for (int nl = 0; nl < 4; ++nl) {
+        int const n = 4 * half + nl;
+        size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
+        C8_UNROLL
+        for (int i = 0; i < 3; ++i)  // u rows of node n: block (0, ib)
+          ex.add(sa.A[0][ib] + nptr * (3 * neqb) + (size_t)i * deg * neqb + pos * neqb + eqb, r.J[4 * nl + i], ATOMIC);
+        ex.add(sa.A[1][ib] + nptr * neqb + pos * neqb + eqb, r.J[4 * nl + 3], ATOMIC);  // p row: block (1, ib)
+      }
+      if (half == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, ATOMIC);
+    };
+    if (sa.atomic) scatter_all(std::integral_constant<int, 1>{});
+    else scatter_all(std::integral_constant<int, 0>{});
     if (lane == 0 && sh.failed) ex.flag(sa.status);
   });
 }

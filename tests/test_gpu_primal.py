@@ -166,4 +166,6 @@ def test_device_adjoint_driver_gradient():
         pp[act] += h * direction
         pm[act] -= h * direction
         errs.append(abs((solve(pp).qoi() - solve(pm).qoi()) / (2 * h) - gd))
-    assert min(errs) < 1e-6 * abs(gd) and np.log10(max(errs) / min(errs)) > 3, (errs, gd)
+    # this bar problem is nearly linear in the parameters: central differences agree with the adjoint at every
+    # step size (no visible error drop), so the check is the agreement itself
+    assert min(errs) < 1e-7 * abs(gd) and max(errs) < 1e-4 * abs(gd), (errs, gd)

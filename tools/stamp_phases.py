@@ -1,0 +1,41 @@
+"""Diagnostic only (build with -DC8_STAMPS): per-phase s_memtime shares of the wave kernel.
+The stamps are written over a slice of the p-residual output, so the outputs of this build are invalid."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from calibr8_amd import Assembler, brick_mesh
+from meshes import prescribed_fields
+
+J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+n = 100
+coords, conn = brick_mesh(n, n, n)
+asm = Assembler(8, coords, conn, "small_J2", J2, scatter="atomic")
+u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+u, p = asm.dev(u_h), asm.dev(p_h)
+u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
+xi0, xi = asm.new_state(), asm.new_state()
+ls = asm.new_linsys()
+for _ in range(3):
+    asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls)
+torch.cuda.synchronize()
+import ctypes as C
+buf = np.zeros(4096 * 16, dtype=np.uint64)
+asm.L.c8_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+asm.L.c8_debug_stamps(asm.h, buf.ctypes.data_as(C.c_void_p))
+raw = buf.reshape(4096, 16)[:, :10].astype(np.int64)
+d = np.diff(raw, axis=1)
+names = ["load+shape+interp", "newton", "inverse", "D pass0", "P pass0", "D pass1", "P pass1", "(loop end)", "scatter"]
+plastic = (xi[:4096, :, 6] > 0).any(dim=1).cpu().numpy()
+for label, sel in (("all", np.ones(4096, bool)), ("elastic elems", ~plastic), ("plastic elems", plastic)):
+    if sel.sum() == 0:
+        continue
+    tot = (raw[sel, 9] - raw[sel, 0]).mean()
+    print("%s (%d): total %.0f cycles" % (label, sel.sum(), tot))
+    for k, nm in enumerate(names):
+        print("   %-20s %8.0f  %5.1f %%" % (nm, d[sel, k].mean(), 100 * d[sel, k].mean() / tot))
