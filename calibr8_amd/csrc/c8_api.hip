@@ -197,6 +197,12 @@ int c8_set_kernel_variant(c8_ctx* c, int variant) {
   c->kernel_variant = variant;
   return C8_OK;
 }
+#ifdef C8_STAMPS
+int c8_debug_stamps(c8_ctx* c, unsigned long long* out) {  // diagnostic build only, not in c8.h
+  C8_HIP(hipMemcpy(out, c->d_stamps, 4096 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return C8_OK;
+}
+#endif
 int c8_set_async(c8_ctx* c, int async) {
   if (!c) return fail(C8_ERR_ARG, "c8_set_async: null ctx");
   c->async = async ? 1 : 0;
@@ -227,6 +233,10 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
   bool const colored = scatters && (c->scatter_mode == C8_SCATTER_COLORED);
   sa.status = c->d_status;
   sa.atomic = colored ? 0 : 1;
+#ifdef C8_STAMPS
+  if (!c->d_stamps) C8_HIP(hipMalloc((void**)&c->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
+  sa.stamps = c->d_stamps;
+#endif
   LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
   if (colored) {
     int const nc = (int)c->color_off.size() - 1;

@@ -37,6 +37,7 @@ struct c8_ctx {
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
   int* d_status = nullptr;
+  unsigned long long* d_stamps = nullptr;  // -DC8_STAMPS diagnostic build only
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
   int kernel_variant = C8_KERNEL_AUTO;

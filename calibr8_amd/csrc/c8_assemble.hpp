@@ -70,6 +70,9 @@ struct SystemArgs {
   double* b[2];     // residual vectors
   int* status;      // device int: set nonzero when a local Newton solve fails
   int atomic;       // 1: atomic adds; 0: plain read-modify-write (colour-batched launch)
+#ifdef C8_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: [4096][16] s_memtime stamps of sampled elements
+#endif
 };
 
 // ---- per-group shared scratch (LDS) -------------------------------------------

@@ -20,6 +20,12 @@
 // Requires an element with 32 DOFs, 8 coupled points and identical point sets for both ip
 // sets (hex8): the two ip sets are fused by adding the pressure-mass flux to V_p.
 #pragma once
+// Diagnostic build only (-DC8_STAMPS, tools/stamp_phases.py): s_memtime stamps at phase boundaries.
+#ifdef C8_STAMPS
+#define C8_STAMP(i) ex.stamp(sa, e, i)
+#else
+#define C8_STAMP(i)
+#endif
 
 #include "c8_assemble.hpp"
 
@@ -174,6 +180,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
   static_assert(E::NDOF == 32 && E::NP0 == 8 && E::SAME_POINTS, "wave kernel needs a hex8-like element");
   static_assert(NL <= 8, "at most 8 local unknowns per point");
 
+  C8_STAMP(0);
   // ---- load: lanes 0..31 = element DOF slots; shape tables: lane = point*8 + node ----------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
@@ -222,6 +229,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
   });
   ex.sync();
 
+  C8_STAMP(1);
   // ---- phase N: local Newton at all 8 points (small_J2.cpp:122-173) ---------------------------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
@@ -304,6 +312,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     }
   });
   ex.sync();
+  C8_STAMP(2);
   // ---- (dC/dxi)^-1 once per point, in the 8-lane layout: lane d solves for unit vector e_d.  Both passes
   //      of phase D then apply it as a matrix-vector product instead of two more eliminations.  When every
   //      point of the element took the elastic branch dC/dxi is exactly I (R = xi - xi_trial) and the
@@ -341,6 +350,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     }
   }
 
+  C8_STAMP(3);
   // ---- phases D and P, 4 points per pass -------------------------------------------------------------
   for (int t = 0; t < 2; ++t) {
     ex.each([&](int lane) {
@@ -402,6 +412,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       }
     });
     ex.sync();
+    C8_STAMP(4 + 2 * t);
     // phase P: lane = (half, column b); J[al] = entry (row of local node al/4.. , col b)
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
@@ -467,8 +478,10 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       }
     });
     ex.sync();
+    C8_STAMP(5 + 2 * t);
   }
 
+  C8_STAMP(8);
   // ---- scatter: lane (half, b) holds the entries (rows of nodes 4*half..4*half+3, column b); the adjoint
   //      assembly stores them transposed (evaluations.cpp:463-465) ------------------------------------------
   ex.each([&](int lane) {
@@ -499,6 +512,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     else scatter_all(std::integral_constant<int, 0>{});
     if (lane == 0 && sh.failed) ex.flag(sa.status);
   });
+  C8_STAMP(9);
 }
 
 template <class E, template <class> class ModelT, class EX>

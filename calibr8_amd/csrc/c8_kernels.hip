@@ -40,6 +40,16 @@ template <class Lane> struct GpuExec {
     else *p += v;
   }
   __device__ __forceinline__ void flag(int* s) { atomicOr(s, 1); }
+#ifdef C8_STAMPS
+  // element e is sampled when e % 244 == 0 (4096 samples over a 1M-element mesh)
+  __device__ __forceinline__ void stamp(SystemArgs const& sa, int e, int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k == 0 && sa.stamps && (e % 244) == 0 && e / 244 < 4096) sa.stamps[(size_t)(e / 244) * 16 + i] = t;
+  }
+#endif
 };
 
 // XCD-aware block remap: the dispatcher deals workgroups round-robin over the 8 XCDs
