@@ -9,6 +9,7 @@ SOURCES = ["c8_kernels.hip", "c8_api.hip", "c8_primal.hip", "c8_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 if os.environ.get("C8_STAMPS"):  # diagnostic build for tools/stamp_phases.py; its outputs are timing shares only
     FLAGS.append("-DC8_STAMPS")
+FLAGS += os.environ.get("C8_EXTRA_FLAGS", "").split()  # kernel experiments (-D switches), never for shipped builds
 
 
 def _stale():
