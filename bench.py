@@ -73,10 +73,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--edge", dest="n", type=int, default=100, help="brick edge (elements) per GPU")
-    ap.add_argument("--scatter", default="atomic", choices=["colored", "atomic"])
+    ap.add_argument("--scatter", default="atomic", choices=["colored", "atomic", "gather"])
     ap.add_argument("--cpu-sample", type=int, default=32, help="edge of the CPU-baseline sample brick")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
+    ap.add_argument("--stage-chunk", type=int, default=0, help="scatter=gather: minimum elements per staged chunk")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on one GPU (halo staged through the host)")
@@ -112,6 +113,8 @@ def main():
     asm = Assembler(8, coords, part.conn, "small_J2", J2, device=str(dev), scatter=args.scatter,
                     extra_pairs=plan.extra_pairs)
     asm.set_kernel(args.kernel)
+    if args.stage_chunk > 0:
+        asm.set_stage_chunk(args.stage_chunk)
     halo = D.Halo(plan, asm.rowptr[0][0], asm.colidx[0][0], device=dev)
     # prescribed state of SURVEY.md 8d on the rank's own block (local coordinates of the block)
     origin = coords[: part.ntouched].min(axis=0)

@@ -145,8 +145,12 @@ class Assembler:
         _l.check(self.L.c8_set_active_params(self.h, es, len(a), a.ctypes.data_as(_l.i32p)))
 
     def set_scatter(self, mode):
-        m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC}[mode]
+        m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC, "gather": _l.C8_SCATTER_GATHER}[mode]
         _l.check(self.L.c8_set_scatter_mode(self.h, m))
+
+    def set_stage_chunk(self, min_chunk):
+        """scatter='gather': smallest chunk of elements staged at a time (default 8192)"""
+        _l.check(self.L.c8_set_stage_chunk(self.h, int(min_chunk)))
 
     def set_kernel(self, variant):
         """'auto' | 'slot' (one lane group per element) | 'wave' (one wavefront per hex8 element)"""

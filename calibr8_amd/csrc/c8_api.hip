@@ -44,6 +44,7 @@ static int model_id(char const* name, int* nloc, int* nparams) {
   return MODEL_NONE;
 }
 
+static void stage_release(c8_ctx* c);
 static int upload_active(c8_ctx* c) {
   std::vector<int32_t> tab((size_t)c->mesh.nsets * 10, 0);
   int ofs = 0;
@@ -116,6 +117,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   if ((rc = upload(&c->d_conn, c->mesh.conn)) || (rc = upload(&c->d_coords, c->mesh.coords)) ||
       (rc = upload(&c->d_nodeptr, c->graph.nodeptr)) || (rc = upload(&c->d_nodeadj, c->graph.nodeadj)) || (rc = upload(&c->d_pos, c->graph.pos)) ||
       (rc = upload(&c->d_elem_set, c->mesh.elem_set)) || (rc = upload(&c->d_order, c->order)) ||
+      (rc = upload(&c->d_nodeelem_ptr, c->graph.nodeelem_ptr)) || (rc = upload(&c->d_nodeelem, c->graph.nodeelem)) ||
       (rc = upload(&c->d_params, c->params)) || (rc = upload_active(c))) {
     c8_destroy(c);
     return rc;
@@ -130,7 +132,8 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
 
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
+  stage_release(c);
+  void* bufs[] = {c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
@@ -186,8 +189,19 @@ int c8_set_stream(c8_ctx* c, void* s) {
   return C8_OK;
 }
 int c8_set_scatter_mode(c8_ctx* c, int mode) {
-  if (!c || (mode != C8_SCATTER_ATOMIC && mode != C8_SCATTER_COLORED)) return fail(C8_ERR_ARG, "c8_set_scatter_mode: bad argument");
+  if (!c || (mode != C8_SCATTER_ATOMIC && mode != C8_SCATTER_COLORED && mode != C8_SCATTER_GATHER)) return fail(C8_ERR_ARG, "c8_set_scatter_mode: bad argument");
+  if (mode == C8_SCATTER_GATHER) {
+    if (!c->ks.gather_rows) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: staged (gather) assembly needs hex8 elements");
+    if (c->graph.max_degree > c8::GATHER_MAX_DEGREE) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: node degree too large for staged (gather) assembly");
+  }
   c->scatter_mode = mode;
+  return C8_OK;
+}
+int c8_set_stage_chunk(c8_ctx* c, int min_chunk) {
+  if (!c || min_chunk < 1) return fail(C8_ERR_ARG, "c8_set_stage_chunk: bad argument");
+  C8_HIP(hipDeviceSynchronize());
+  stage_release(c);  // the plan is rebuilt at the next staged assembly
+  c->stage_min_chunk = min_chunk;
   return C8_OK;
 }
 int c8_set_kernel_variant(c8_ctx* c, int variant) {
@@ -226,6 +240,45 @@ static MeshTables tables(c8_ctx const* c, bool colored) {
   return MeshTables{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, colored ? c->d_order : nullptr, c->d_params};
 }
 
+// Staged (gather) assembly on the caller's stream: chunk k of the elements is assembled into the stage ring,
+// then the rows of the nodes whose last element lies in chunk k are summed.  A node's elements lie in at most
+// two consecutive chunks (StagePlan), so a ring of three chunks is enough; chunking only bounds the size of the
+// stage (8.4 KB per element), the two kernels of a chunk run one after the other (the assembly kernel fills
+// the register file and LDS of every CU, so the row sums cannot run beside it).
+static int stage_setup(c8_ctx* c) {
+  if (c->d_stage) return C8_OK;
+  plan_staged_assembly(c->mesh, c->graph, c->stage_min_chunk, c->stage_min_chunk >= 256 ? 256 : 4, c->plan);
+  size_t const bytes = (size_t)c->plan.ring * c->ks.stage_stride * sizeof(double);
+  if (hipMalloc((void**)&c->d_stage, bytes) != hipSuccess) return fail(C8_ERR_DEVICE, "staged assembly: cannot allocate the element stage");
+  return upload(&c->d_node_order, c->plan.node_order);
+}
+static void stage_release(c8_ctx* c) {
+  (void)hipFree(c->d_stage);
+  (void)hipFree(c->d_node_order);
+  c->d_stage = nullptr;
+  c->d_node_order = nullptr;
+}
+
+static MeshTables tables(c8_ctx const* c, bool colored);
+static int run_staged(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& aa, SystemArgs sa) {
+  int rc = stage_setup(c);
+  if (rc) return rc;
+  StagePlan const& pl = c->plan;
+  sa.status = c->d_status;
+  sa.atomic = 0;
+  sa.stage = c->d_stage;
+  sa.stage_ring = pl.ring;
+  GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, c->d_stage, pl.ring, c->d_node_order,
+                {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
+  for (int k = 0; k < pl.nchunks; ++k) {
+    LaunchArgs a{tables(c, false), c->ms, fa, aa, sa, k * pl.chunk, std::min(pl.chunk, c->mesh.nelems - k * pl.chunk), c->stream};
+    C8_HIP(fn(a));
+    C8_HIP(c->ks.gather_rows(ga, pl.node_off[k], pl.node_off[k + 1] - pl.node_off[k], c->graph.max_degree, c->stream));
+  }
+  if (c->async) return C8_OK;
+  return c8_status(c);
+}
+
 // run one launcher over the whole mesh: one launch per colour, or one atomic launch.
 // `scatters` = the kernel adds into shared A/b entries (needs colouring or atomics).
 static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& aa, SystemArgs sa, bool scatters, char const* what) {
@@ -237,6 +290,13 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
   if (!c->d_stamps) C8_HIP(hipMalloc((void**)&c->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
   sa.stamps = c->d_stamps;
 #endif
+  // staged assembly: the two Jacobian assemblies through their wave kernels; everything else (residual-only
+  // assembly: 32 adds per element) keeps atomic adds
+  bool const staged = scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] &&
+                      (fn == c->ks.forward_jacobian_wave || fn == c->ks.adjoint_jacobian_wave);
+  if (scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !staged)
+    return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly needs the wave-per-element kernels");
+  if (staged) return run_staged(c, fn, fa, aa, sa);
   LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
   if (colored) {
     int const nc = (int)c->color_off.size() - 1;

@@ -34,6 +34,12 @@ struct c8_ctx {
   uint8_t* d_pos = nullptr;
   int32_t* d_elem_set = nullptr;
   int32_t* d_order = nullptr;
+  int32_t* d_nodeelem_ptr = nullptr;  // node -> elements (staged assembly)
+  int32_t* d_nodeelem = nullptr;
+  double* d_stage = nullptr;          // [ring][stage_stride], allocated at the first staged assembly
+  int32_t* d_node_order = nullptr;
+  c8::StagePlan plan;                 // staged assembly: chunks, ring, node order
+  int stage_min_chunk = 131072;
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
   int* d_status = nullptr;

@@ -70,10 +70,30 @@ struct SystemArgs {
   double* b[2];     // residual vectors
   int* status;      // device int: set nonzero when a local Newton solve fails
   int atomic;       // 1: atomic adds; 0: plain read-modify-write (colour-batched launch)
+  double* stage;    // not null: element matrices are stored element-major here and summed by gather_node_rows
+  int stage_ring;   // element slots in the stage: element e uses slot e % stage_ring
 #ifdef C8_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [4096][16] s_memtime stamps of sampled elements
 #endif
 };
+
+// Staged assembly (scatter mode GATHER): the assembly kernels store every element matrix, as it stands in
+// registers, to stage[e][STAGE_STRIDE] with fully coalesced stores; gather_node_rows then sums the rows of each
+// node over the node's elements in a fixed order and adds them to the CSR values.  No atomics, no colouring,
+// bitwise reproducible.
+struct GatherArgs {
+  int32_t const* nodeptr;       // node graph
+  uint8_t const* pos;           // [nelems][NN(col node)][NN(row node)]
+  int32_t const* nodeelem_ptr;  // [nnodes+1]
+  int32_t const* nodeelem;      // (element << 3) | local node
+  double const* stage;          // [stage_ring][stage_stride]
+  int stage_ring;               // element e is in slot e % stage_ring
+  int32_t const* node_order;    // nodes to process (StagePlan::node_order)
+  double* A[2][2];
+  double* b[2];
+};
+template <class E> constexpr int stage_stride() { return E::NDOF * E::NDOF + E::NDOF; }
+constexpr int GATHER_MAX_DEGREE = 64;  // node-graph rows the gather kernel's LDS accumulator can hold
 
 // ---- per-group shared scratch (LDS) -------------------------------------------
 template <class E, int NL> struct GroupShared {

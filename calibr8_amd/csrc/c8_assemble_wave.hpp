@@ -230,6 +230,11 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
   ex.sync();
 
   C8_STAMP(1);
+#ifdef C8_EXPERIMENT_SCATTER_ONLY  // timing experiment only: loads and adds, no arithmetic
+  if (sa.atomic == 12345) {
+#else
+  {
+#endif
   // ---- phase N: local Newton at all 8 points (small_J2.cpp:122-173) ---------------------------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
@@ -395,28 +400,36 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       MechFlux<Dual> f;
       Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
       f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);  // ip set 1 has the same points and weights
+      // the quadrature weight w*dv goes into D and F here (13 products per lane and pass) rather than
+      // into every product of phase P
+      double const w = sh.wdv[pt];
       double* Dc = &sh.D[ql][0][c];
       constexpr int LD = WQ + 1;
-      Dc[0 * LD] = f.Gu.xx.d; Dc[1 * LD] = f.Gu.xy.d; Dc[2 * LD] = f.Gu.xz.d;
-      Dc[3 * LD] = f.Gu.yx.d; Dc[4 * LD] = f.Gu.yy.d; Dc[5 * LD] = f.Gu.yz.d;
-      Dc[6 * LD] = f.Gu.zx.d; Dc[7 * LD] = f.Gu.zy.d; Dc[8 * LD] = f.Gu.zz.d;
-      Dc[9 * LD] = f.Vp.d;
-      Dc[10 * LD] = f.Gp[0].d; Dc[11 * LD] = f.Gp[1].d; Dc[12 * LD] = f.Gp[2].d;
-      if (c == 0) {
+      Dc[0 * LD] = w * f.Gu.xx.d; Dc[1 * LD] = w * f.Gu.xy.d; Dc[2 * LD] = w * f.Gu.xz.d;
+      Dc[3 * LD] = w * f.Gu.yx.d; Dc[4 * LD] = w * f.Gu.yy.d; Dc[5 * LD] = w * f.Gu.yz.d;
+      Dc[6 * LD] = w * f.Gu.zx.d; Dc[7 * LD] = w * f.Gu.zy.d; Dc[8 * LD] = w * f.Gu.zz.d;
+      Dc[9 * LD] = w * f.Vp.d;
+      Dc[10 * LD] = w * f.Gp[0].d; Dc[11 * LD] = w * f.Gp[1].d; Dc[12 * LD] = w * f.Gp[2].d;
+      if (c == 0 && !ADJOINT) {
         double* Fp = sh.F[pt];
-        Fp[0] = f.Gu.xx.v; Fp[1] = f.Gu.xy.v; Fp[2] = f.Gu.xz.v;
-        Fp[3] = f.Gu.yx.v; Fp[4] = f.Gu.yy.v; Fp[5] = f.Gu.yz.v;
-        Fp[6] = f.Gu.zx.v; Fp[7] = f.Gu.zy.v; Fp[8] = f.Gu.zz.v;
-        Fp[9] = f.Vp.v;
-        Fp[10] = f.Gp[0].v; Fp[11] = f.Gp[1].v; Fp[12] = f.Gp[2].v;
+        Fp[0] = w * f.Gu.xx.v; Fp[1] = w * f.Gu.xy.v; Fp[2] = w * f.Gu.xz.v;
+        Fp[3] = w * f.Gu.yx.v; Fp[4] = w * f.Gu.yy.v; Fp[5] = w * f.Gu.yz.v;
+        Fp[6] = w * f.Gu.zx.v; Fp[7] = w * f.Gu.zy.v; Fp[8] = w * f.Gu.zz.v;
+        Fp[9] = w * f.Vp.v;
+        Fp[10] = w * f.Gp[0].v; Fp[11] = w * f.Gp[1].v; Fp[12] = w * f.Gp[2].v;
       }
     });
     ex.sync();
     C8_STAMP(4 + 2 * t);
-    // phase P: lane = (half, column b); J[al] = entry (row of local node al/4.. , col b)
+    // phase P: lane = (g, column b).  The rows of the element matrix are split by flux group, so that no
+    // product of the contraction W^T (D B) is formed twice:
+    //   g = 0: entries (node n, u_0) from flux rows 0..2 and (n, u_1) from flux rows 3..5,   n = 0..7
+    //   g = 1: entries (node n, u_2) from flux rows 6..8 and (n, p)   from flux rows 9..12
+    // Both halves run one instruction stream: entry E0 takes rows r0..r0+2, entry E1 rows r1..r1+2 plus
+    // row 9 with weight zf (zero for g = 0).  J[2n] = E0 of node n, J[2n+1] = E1 of node n.
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
-      int const b = lane & 31, half = lane >> 5;
+      int const b = lane & 31, g = lane >> 5;
       bool const bu = b < 3 * E::NN;
       int const m = bu ? b / 3 : b - 3 * E::NN;
       int const k = bu ? b - 3 * m : 0;
@@ -426,50 +439,45 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       // skipped under a lane-dependent branch (a branch per row serialises the LDS reads of this loop)
       bool const has_cv = Mechanics::USES_U || !bu;
       int const cvl = has_cv ? cv : 9;
+      int const r0 = 6 * g, r1 = 3 + 7 * g;
+      double const zf = g ? 1. : 0.;
       C8_NOUNROLL
       for (int ql = 0; ql < 4; ++ql) {
         int const pt = 4 * t + ql;
-        double const w = sh.wdv[pt];
         double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
         double const bNv = has_cv ? bN : 0.;
         double const bNp = bu ? 0. : bN;
+        double s0, s1, s2, u0, u1, u2, u3, v0 = 0., v1 = 0.;
         if (!ADJOINT) {
-          double T[WF];  // T[r] = w * sum_c D[r][c] dq_c/dx_b
-          C8_UNROLL
-          for (int rr = 0; rr < WF; ++rr) {
+          // (D B)[rr][b] = sum_c D[rr][c] dq_c/dx_b   (D already carries w*dv)
+          auto DB = [&](int rr) {
             double const* Dr = sh.D[ql][rr];
-            T[rr] = w * (Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cvl] * bNv);
-          }
-          C8_UNROLL
-          for (int nl = 0; nl < 4; ++nl) {
-            int const n = 4 * half + nl;
-            double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
-            r.J[4 * nl + 0] += a0 * T[0] + a1 * T[1] + a2 * T[2];
-            r.J[4 * nl + 1] += a0 * T[3] + a1 * T[4] + a2 * T[5];
-            r.J[4 * nl + 2] += a0 * T[6] + a1 * T[7] + a2 * T[8];
-            r.J[4 * nl + 3] += aN * T[9] + a0 * T[10] + a1 * T[11] + a2 * T[12];
-          }
+            return Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cvl] * bNv;
+          };
+          s0 = DB(r0); s1 = DB(r0 + 1); s2 = DB(r0 + 2);
+          u0 = DB(r1); u1 = DB(r1 + 1); u2 = DB(r1 + 2);
+          u3 = zf * DB(9);
         } else {
           // transposed element matrix computed directly, so that the lanes of one scatter instruction
-          // still share a CSR row: lane = element ROW a (flux side), loop over element COLUMNS (q side)
-          double U[WQ];  // U[c] = w * sum_r dR_a/dflux_r D[r][c]
-          C8_UNROLL
-          for (int c = 0; c < WQ; ++c) {
-            U[c] = w * (sh.D[ql][cg][c] * b0 + sh.D[ql][cg + 1][c] * b1 + sh.D[ql][cg + 2][c] * b2 + sh.D[ql][9][c] * bNp);
-          }
-          C8_UNROLL
-          for (int nl = 0; nl < 4; ++nl) {
-            int const n = 4 * half + nl;
-            double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
-            r.J[4 * nl + 0] += a0 * U[0] + a1 * U[1] + a2 * U[2] + (Mechanics::USES_U ? aN * U[13] : 0.);
-            r.J[4 * nl + 1] += a0 * U[3] + a1 * U[4] + a2 * U[5] + (Mechanics::USES_U ? aN * U[14] : 0.);
-            r.J[4 * nl + 2] += a0 * U[6] + a1 * U[7] + a2 * U[8] + (Mechanics::USES_U ? aN * U[15] : 0.);
-            r.J[4 * nl + 3] += aN * U[9] + a0 * U[10] + a1 * U[11] + a2 * U[12];
-          }
+          // still share a CSR row: lane = element ROW a (flux side), entries = element COLUMNS (q side):
+          // (W^T D)[a][c] = sum_r dR_a/dflux_r D[r][c]
+          auto WD = [&](int c) {
+            return sh.D[ql][cg][c] * b0 + sh.D[ql][cg + 1][c] * b1 + sh.D[ql][cg + 2][c] * b2 + sh.D[ql][9][c] * bNp;
+          };
+          s0 = WD(r0); s1 = WD(r0 + 1); s2 = WD(r0 + 2);
+          u0 = WD(r1); u1 = WD(r1 + 1); u2 = WD(r1 + 2);
+          u3 = zf * WD(9);
+          if (Mechanics::USES_U) { v0 = WD(13 + 2 * g); v1 = (1. - zf) * WD(14); }
+        }
+        C8_UNROLL
+        for (int n = 0; n < E::NN; ++n) {
+          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+          r.J[2 * n] += a0 * s0 + a1 * s1 + a2 * s2 + ((ADJOINT && Mechanics::USES_U) ? aN * v0 : 0.);
+          r.J[2 * n + 1] += a0 * u0 + a1 * u1 + a2 * u2 + aN * u3 + ((ADJOINT && Mechanics::USES_U) ? aN * v1 : 0.);
         }
         if (!ADJOINT) {  // residual entry b from the flux values (both halves compute it, half 0 stores it)
           double const* Fp = sh.F[pt];
-          r.R += w * (Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * bNp);
+          r.R += Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * bNp;
         } else {  // rhs_b = sum_c [-dJ/dq_c + (dxi/dq_c).g] dq_c/dx_b + f_b  (:486-487)
           double const* rq = sh.rq[ql];
           r.R += rq[cg] * b0 + rq[cg + 1] * b1 + rq[cg + 2] * b2 + rq[cv] * bN +
@@ -481,39 +489,170 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     C8_STAMP(5 + 2 * t);
   }
 
+  }
   C8_STAMP(8);
-  // ---- scatter: lane (half, b) holds the entries (rows of nodes 4*half..4*half+3, column b); the adjoint
-  //      assembly stores them transposed (evaluations.cpp:463-465) ------------------------------------------
+  // ---- scatter: lane (g, b) holds column b of the rows (n, u_2g) [J[2n]] and (n, u_1) or (n, p) [J[2n+1]];
+  //      the adjoint assembly stores them transposed (evaluations.cpp:463-465) ------------------------------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
-    int const b = lane & 31, half = lane >> 5;
+    int const b = lane & 31, g = lane >> 5;
     int ib, nb, eqb;
     slot_to_dof<E>(b, ib, nb, eqb);
     int const neqb = ib == 0 ? 3 : 1;
     uint8_t const* posb = mt.pos + ((size_t)e * E::NN + nb) * E::NN;  // pos[e][col node nb][row node]
     // forward: J[(n,i)][b]; adjoint: the lane already holds the transposed entries J[b][(n,i)], so in both
-    // cases this is assembled entry (row (n,i), column b) and the lanes of one instruction share rows.
+    // cases this is assembled entry (row (n,i), column b) and the lanes of one instruction share 2 rows.
     // One uniform branch selects atomic or plain adds for the whole batch (a branch per add would keep the
     // adds from being issued back to back).
+    double* const A0 = sa.A[0][ib];                 // u rows: block (0, ib)
+    double* const A1 = g ? sa.A[1][ib] : A0;        // second entry: p row (block (1, ib)) or u row 1
     auto scatter_all = [&](auto mode) {
       constexpr int ATOMIC = decltype(mode)::value;
       C8_UNROLL
-      for (int nl = 0; nl < 4; ++nl) {
-        int const n = 4 * half + nl;
+      for (int n = 0; n < E::NN; ++n) {
         size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
-        C8_UNROLL
-        for (int i = 0; i < 3; ++i)  // u rows of node n: block (0, ib)
-          ex.add(sa.A[0][ib] + nptr * (3 * neqb) + (size_t)i * deg * neqb + pos * neqb + eqb, r.J[4 * nl + i], ATOMIC);
-        ex.add(sa.A[1][ib] + nptr * neqb + pos * neqb + eqb, r.J[4 * nl + 3], ATOMIC);  // p row: block (1, ib)
+        size_t const in_row = pos * neqb + eqb;
+        size_t const urow0 = nptr * (3 * neqb);     // first u row of node n in block (0, ib)
+        ex.add(A0 + urow0 + (size_t)(2 * g) * deg * neqb + in_row, r.J[2 * n], ATOMIC);
+        ex.add(A1 + (g ? nptr * neqb : urow0 + deg * neqb) + in_row, r.J[2 * n + 1], ATOMIC);
       }
-      if (half == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, ATOMIC);
+      if (g == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, ATOMIC);
     };
-    if (sa.atomic) scatter_all(std::integral_constant<int, 1>{});
-    else scatter_all(std::integral_constant<int, 0>{});
+#ifdef C8_EXPERIMENT_NO_SCATTER  // timing experiment only: everything but the adds
+    if (r.J[0] == 1.2345e300) scatter_all(std::integral_constant<int, 1>{});
+#else
+    if (sa.stage) {  // staged assembly: registers -> stage[e] as they stand, 512 contiguous bytes per store
+      double* const st = sa.stage + (size_t)(e % sa.stage_ring) * stage_stride<E>();
+      C8_UNROLL
+      for (int a = 0; a < 16; ++a) st[a * 64 + lane] = r.J[a];
+      if (g == 0) st[E::NDOF * E::NDOF + b] = r.R;
+    } else if (sa.atomic) {
+#ifdef C8_EXPERIMENT_SKIP_PCOL  // timing experiment only: no adds into the p columns (blocks (0,1) and (1,1))
+      if (b < 3 * E::NN)
+#endif
+      scatter_all(std::integral_constant<int, 1>{});
+    } else {
+      scatter_all(std::integral_constant<int, 0>{});
+    }
+#endif
     if (lane == 0 && sh.failed) ex.flag(sa.status);
   });
   C8_STAMP(9);
 }
+
+// ---- staged assembly, second half: the rows of one node summed over the node's elements ---------------------
+// One wavefront per node.  stage[e][(2n + entry) * 64 + lane] holds, for lane = (g, b), column b of row
+// (n, u_2g) [entry 0] and of row (n, u_1) or (n, p) [entry 1] (wave_scatter's register layout).  The wave
+// adds the contributions of the node's elements, in ascending element order, into acc[pos][row][col] (LDS:
+// pos = position of the column node in this node's graph row) and then adds the finished rows to the four
+// CSR blocks and the node's residual entries to b with contiguous accesses.
+template <class E, int MAXDEG> struct GatherShared {
+  double acc[MAXDEG][16];
+};
+
+template <int MAXDEG> struct GatherLane {
+  static constexpr int N00 = (9 * MAXDEG + 63) / 64, N01 = (3 * MAXDEG + 63) / 64;
+  double v0[8], v1[8], rv[8];
+  int pos[8];
+  double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
+  double rsum;
+};
+
+template <class E, int MAXDEG, class EX>
+C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs const& ga, int node) {
+  static_assert(E::NDOF == 32 && E::NN == 8, "staged assembly is implemented for hex8");
+  constexpr int CH = 8;  // elements whose rows are in flight together
+  using GL = GatherLane<MAXDEG>;
+  int const nptr = ga.nodeptr[node], deg = ga.nodeptr[node + 1] - nptr;
+  int const e0 = ga.nodeelem_ptr[node], e1 = ga.nodeelem_ptr[node + 1];
+  size_t const np = (size_t)nptr;
+  int const n3 = 3 * deg;
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    // the CSR entries this lane will update: loaded now, so that their round trip overlaps the stage loads.
+    // Block (0,0): the node's three u rows are contiguous (3*deg entries each), one run of 9*deg values;
+    // blocks (0,1) and (1,0): runs of 3*deg values; block (1,1): deg values.
+    C8_UNROLL
+    for (int it = 0; it < GL::N00; ++it) {
+      int const j = lane + 64 * it;
+      if (j < 9 * deg) r.a00[it] = ga.A[0][0][np * 9 + j];
+    }
+    C8_UNROLL
+    for (int it = 0; it < GL::N01; ++it) {
+      int const j = lane + 64 * it;
+      if (j < n3) { r.a01[it] = ga.A[0][1][np * 3 + j]; r.a10[it] = ga.A[1][0][np * 3 + j]; }
+    }
+    if (lane < deg) r.a11 = ga.A[1][1][np + lane];
+    C8_UNROLL
+    for (int it = 0; it < MAXDEG / 4; ++it) {
+      int const q = lane + 64 * it;
+      if (q < deg * 16) (&sh.acc[0][0])[q] = 0.;
+    }
+    r.rsum = 0.;
+  });
+  ex.sync();
+  for (int c0 = e0; c0 < e1; c0 += CH) {
+    // all loads of the chunk first (independent HBM round trips), then the adds in element order
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const b = lane & 31;
+      bool const bu = b < 3 * E::NN;
+      int const m = bu ? b / 3 : b - 3 * E::NN;
+      C8_UNROLL
+      for (int k = 0; k < CH; ++k) {
+        r.pos[k] = -1;
+        if (c0 + k < e1) {
+          int const packed = ga.nodeelem[c0 + k];
+          int const e = packed >> 3, ln = packed & 7;
+          double const* const st = ga.stage + (size_t)(e % ga.stage_ring) * stage_stride<E>();
+          r.pos[k] = ga.pos[((size_t)e * E::NN + m) * E::NN + ln];
+          r.v0[k] = st[(2 * ln) * 64 + lane];
+          r.v1[k] = st[(2 * ln + 1) * 64 + lane];
+          r.rv[k] = (lane < 4) ? st[E::NDOF * E::NDOF + (lane < 3 ? 3 * ln + lane : 3 * E::NN + ln)] : 0.;
+        }
+      }
+    });
+    C8_UNROLL
+    for (int k = 0; k < CH; ++k) {
+      if (c0 + k >= e1) break;
+      ex.each([&](int lane) {
+        auto& r = ex.lane(lane);
+        int const b = lane & 31, g = lane >> 5;
+        int const col = (b < 3 * E::NN) ? b % 3 : 3;
+        sh.acc[r.pos[k]][(2 * g) * 4 + col] += r.v0[k];         // row u_2g
+        sh.acc[r.pos[k]][(g ? 3 : 1) * 4 + col] += r.v1[k];     // row p or u_1
+        r.rsum += r.rv[k];
+      });
+      ex.sync();
+    }
+  }
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    C8_UNROLL
+    for (int it = 0; it < GL::N00; ++it) {
+      int const j = lane + 64 * it;
+      if (j < 9 * deg) {
+        int const i = j / n3, jj = j - i * n3, pos = jj / 3, col = jj - 3 * pos;
+        ga.A[0][0][np * 9 + j] = r.a00[it] + sh.acc[pos][i * 4 + col];
+      }
+    }
+    C8_UNROLL
+    for (int it = 0; it < GL::N01; ++it) {
+      int const j = lane + 64 * it;
+      if (j < n3) {
+        int const i = j / deg, pos = j - i * deg;          // block (0,1): rows u_i, deg entries each
+        ga.A[0][1][np * 3 + j] = r.a01[it] + sh.acc[pos][i * 4 + 3];
+        int const pos2 = j / 3, col = j - 3 * pos2;        // block (1,0): the p row, 3*deg entries
+        ga.A[1][0][np * 3 + j] = r.a10[it] + sh.acc[pos2][3 * 4 + col];
+      }
+    }
+    if (lane < deg) ga.A[1][1][np + lane] = r.a11 + sh.acc[lane][15];
+    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] += r.rsum;
+    if (lane == 3) ga.b[1][node] += r.rsum;
+  });
+  ex.sync();
+}
+
 
 template <class E, template <class> class ModelT, class EX>
 C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,

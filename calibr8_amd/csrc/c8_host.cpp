@@ -44,6 +44,19 @@ std::string build_node_graph(HostMesh const& m, HostGraph& g) {
     if (g.nodeadj.size() > (size_t)0x7fffffff / 9) return "node graph too large for int32 CSR offsets";
     g.nodeptr[(size_t)n + 1] = (int32_t)g.nodeadj.size();
   }
+  g.max_degree = 0;
+  for (int n = 0; n < m.nnodes; ++n) g.max_degree = std::max(g.max_degree, (int)(g.nodeptr[n + 1] - g.nodeptr[n]));
+  // node -> elements (gather-mode assembly sums a node's rows over its elements, in ascending element order)
+  if (nn > 8 || m.nelems >= (1 << 28)) return "node-to-element table needs nn <= 8 and fewer than 2^28 elements";
+  g.nodeelem_ptr.assign((size_t)m.nnodes + 1, 0);
+  for (size_t q = 0; q < m.conn.size(); ++q) g.nodeelem_ptr[(size_t)m.conn[q] + 1]++;
+  for (int n = 0; n < m.nnodes; ++n) g.nodeelem_ptr[n + 1] += g.nodeelem_ptr[n];
+  g.nodeelem.assign(m.conn.size(), 0);
+  {
+    std::vector<int32_t> fill2(g.nodeelem_ptr.begin(), g.nodeelem_ptr.end() - 1);
+    for (int e = 0; e < m.nelems; ++e)
+      for (int a = 0; a < nn; ++a) g.nodeelem[(size_t)fill2[m.conn[(size_t)e * nn + a]]++] = (e << 3) | a;
+  }
   g.pos.assign((size_t)m.nelems * nn * nn, 0);
   for (int e = 0; e < m.nelems; ++e)
     for (int r = 0; r < nn; ++r) {
@@ -56,6 +69,37 @@ std::string build_node_graph(HostMesh const& m, HostGraph& g) {
       }
     }
   return "";
+}
+
+void plan_staged_assembly(HostMesh const& m, HostGraph const& g, int min_chunk, int align, StagePlan& plan) {
+  int bw = 1;
+  std::vector<int32_t> last((size_t)m.nnodes, -1);
+  for (int n = 0; n < m.nnodes; ++n) {
+    int const a = g.nodeelem_ptr[n], b = g.nodeelem_ptr[n + 1];
+    if (a == b) continue;
+    int const lo = g.nodeelem[a] >> 3, hi = g.nodeelem[b - 1] >> 3;  // lists are ascending
+    bw = std::max(bw, hi - lo + 1);
+    last[n] = hi;
+  }
+  int chunk = std::max(bw, min_chunk);
+  chunk = ((chunk + align - 1) / align) * align;
+  if ((int64_t)chunk * 4 >= m.nelems) {  // not worth a ring
+    plan.chunk = m.nelems;
+    plan.nchunks = 1;
+    plan.ring = m.nelems;
+  } else {
+    plan.chunk = chunk;
+    plan.nchunks = (m.nelems + chunk - 1) / chunk;
+    plan.ring = 3 * chunk;
+  }
+  plan.node_off.assign((size_t)plan.nchunks + 1, 0);
+  for (int n = 0; n < m.nnodes; ++n)
+    if (last[n] >= 0) plan.node_off[(size_t)(last[n] / plan.chunk) + 1]++;
+  for (int k = 0; k < plan.nchunks; ++k) plan.node_off[k + 1] += plan.node_off[k];
+  plan.node_order.assign((size_t)plan.node_off[plan.nchunks], 0);
+  std::vector<int32_t> fill(plan.node_off.begin(), plan.node_off.end() - 1);
+  for (int n = 0; n < m.nnodes; ++n)
+    if (last[n] >= 0) plan.node_order[(size_t)fill[last[n] / plan.chunk]++] = n;
 }
 
 static int const NEQ[2] = {3, 1};

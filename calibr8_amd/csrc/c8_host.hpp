@@ -27,11 +27,26 @@ struct HostGraph {
   std::vector<int32_t> nodeptr;   // [nnodes+1]
   std::vector<int32_t> nodeadj;   // sorted neighbour node ids (a node neighbours itself)
   std::vector<uint8_t> pos;       // [nelems][nn(col node)][nn(row node)]
+  std::vector<int32_t> nodeelem_ptr;  // [nnodes+1] offsets into nodeelem
+  std::vector<int32_t> nodeelem;      // elements of a node, ascending, packed (element << 3) | local node index
+  int max_degree = 0;                 // longest row of the node graph
 };
 
 // Node-to-node graph with sorted rows, plus the per-element position table.
 // Returns an empty string on success, otherwise an error message.
 std::string build_node_graph(HostMesh const& m, HostGraph& g);
+
+// Plan of the staged (gather) assembly: elements are processed in chunks of `chunk` consecutive elements whose
+// matrices go to a ring of `ring` element slots (slot = element mod ring); the rows of a node are summed once
+// the chunk holding its last element is done.  `chunk` is at least the element bandwidth of the mesh (largest
+// spread of element ids around one node), so a node's elements lie in at most two consecutive chunks and a ring
+// of three chunks is enough; meshes too small or too scattered for that get one chunk and ring = nelems.
+struct StagePlan {
+  int chunk = 0, nchunks = 0, ring = 0;
+  std::vector<int32_t> node_order;  // nodes with elements, sorted by the chunk of their last element
+  std::vector<int32_t> node_off;    // [nchunks+1] offsets into node_order
+};
+void plan_staged_assembly(HostMesh const& m, HostGraph const& g, int min_chunk, int align, StagePlan& plan);
 
 // CSR of block (i,j), i,j in {0:u (3 eqs), 1:p (1 eq)}: row dof = node*neq_i+eq_i,
 // columns sorted, all equations of a neighbour node contiguous -- the layout

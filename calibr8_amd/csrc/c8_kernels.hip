@@ -194,6 +194,34 @@ template <class E, template <class> class ModelT> static hipError_t launch_param
   return hipGetLastError();
 }
 
+// staged assembly: one wavefront per node sums the node's rows from the element-major stage
+template <class E, int MAXDEG>
+__global__ void __launch_bounds__(BLOCK) k_gather_rows(GatherArgs ga, int first, int count, int nblocks) {
+  constexpr int WPB = BLOCK / 64;
+  __shared__ GatherShared<E, MAXDEG> shs[WPB];
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int const gi = lb * WPB + wib;
+  if (gi >= count) return;
+  GatherLane<MAXDEG> L;
+  GpuExec<GatherLane<MAXDEG>> ex(lane, L);
+  gather_node_rows<E, MAXDEG>(ex, shs[wib], ga, ga.node_order[first + gi]);
+}
+template <class E> static hipError_t launch_gather_rows(GatherArgs const& ga, int first, int count, int max_degree, hipStream_t stream) {
+  constexpr int WPB = BLOCK / 64;
+  if (count <= 0) return hipSuccess;
+  int const nblocks = (count + WPB - 1) / WPB;
+  int const grid = ((nblocks + 7) / 8) * 8;
+  if (max_degree <= 32)
+    hipLaunchKernelGGL((k_gather_rows<E, 32>), dim3(grid), dim3(BLOCK), 0, stream, ga, first, count, nblocks);
+  else if (max_degree <= GATHER_MAX_DEGREE)
+    hipLaunchKernelGGL((k_gather_rows<E, GATHER_MAX_DEGREE>), dim3(grid), dim3(BLOCK), 0, stream, ga, first, count, nblocks);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // group index -> element for the colour-batched / atomic element-parallel kernels
 #define C8_GROUP_PROLOGUE(E)                                                  \
   constexpr int GPB = BLOCK / E::NDOF;                                        \
@@ -316,12 +344,16 @@ template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get_adjoint() { return nullptr; }
   static LaunchFn get_adjoint_local() { return nullptr; }
   static LaunchFn get_param_gradient() { return nullptr; }
+  static GatherFn get_gather() { return nullptr; }
+  static int stage() { return 0; }
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint() { return &launch_adjoint_jacobian_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint_local() { return &launch_adjoint_local_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_param_gradient() { return &launch_param_gradient_wave<Elem<C8_HEX8>, ModelT>; }
+  static GatherFn get_gather() { return &launch_gather_rows<Elem<C8_HEX8>>; }
+  static int stage() { return stage_stride<Elem<C8_HEX8>>(); }
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
@@ -336,6 +368,8 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;
   ks.param_gradient = &launch_param_gradient<E, ModelT>;
   ks.qoi = &launch_qoi<E, ModelT>;
+  ks.gather_rows = WaveKernel<E, ModelT>::get_gather();
+  ks.stage_stride = WaveKernel<E, ModelT>::stage();
   return ks;
 }
 

@@ -20,6 +20,7 @@ struct LaunchArgs {
 };
 
 typedef hipError_t (*LaunchFn)(LaunchArgs const&);
+typedef hipError_t (*GatherFn)(GatherArgs const&, int first, int count, int max_degree, hipStream_t);
 
 struct KernelSet {
   LaunchFn forward_jacobian;   // K1, one lane group (NDOF lanes) per element
@@ -32,6 +33,8 @@ struct KernelSet {
   LaunchFn adjoint_local_wave;     // K4, one wavefront per element (hex8 only, else null)
   LaunchFn param_gradient_wave;    // K5, one wavefront per element (hex8 only, else null)
   LaunchFn qoi;                // K6
+  GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage (hex8 only, else null)
+  int stage_stride;            // doubles per element in the stage (0 when gather_rows is null)
 };
 
 // registry keyed like the reference's string factories

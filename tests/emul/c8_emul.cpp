@@ -5,6 +5,7 @@
 // shared (LDS) state is a stack object, atomics are plain adds.  This lets the CPU test
 // suite check the kernel algorithms against the oracle without a GPU.  It is not a
 // fallback: nothing under calibr8_amd/ can reach this file.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -29,8 +30,16 @@ template <class Lane, int NDOF> struct CpuExec {
 
 enum { K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
+static int g_last_nchunks = 0;
+extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
+
 struct Call {
   int what;
+  int staged;  // wave Jacobian kernels: staged (gather) assembly instead of direct adds
+  int nnodes;
+  HostGraph const* graph;
+  HostMesh const* mesh;
+  int* nchunks_out;
   int nelems;
   MeshTables mt;
   ModelSettings ms;
@@ -91,9 +100,35 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
   auto* ex = new CpuExec<WaveLane<ModelT>, 64>();
-  for (int e = 0; e < c.nelems; ++e) {
-    if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.sa, e);
-    else adjoint_jacobian_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+  SystemArgs sa = c.sa;
+  if (!c.staged) {
+    for (int e = 0; e < c.nelems; ++e) {
+      if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
+      else adjoint_jacobian_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
+    }
+  } else {
+    // staged assembly in the order the stream pipeline of c8_api.hip produces: chunk k into the ring, then the
+    // rows of the nodes that chunk k completes; a small minimum chunk so that test meshes go round the ring
+    StagePlan pl;
+    plan_staged_assembly(*c.mesh, *c.graph, 1, 1, pl);
+    std::vector<double> stage((size_t)pl.ring * stage_stride<E>(), 0.);
+    sa.stage = stage.data();
+    sa.stage_ring = pl.ring;
+    auto* gsh = new GatherShared<E, GATHER_MAX_DEGREE>();
+    auto* gex = new CpuExec<GatherLane<GATHER_MAX_DEGREE>, 64>();
+    GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), stage.data(), pl.ring,
+                  pl.node_order.data(), {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
+    for (int k = 0; k < pl.nchunks; ++k) {
+      int const e1 = std::min(c.nelems, (k + 1) * pl.chunk);
+      for (int e = k * pl.chunk; e < e1; ++e) {
+        if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
+        else adjoint_jacobian_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
+      }
+      for (int q = pl.node_off[k]; q < pl.node_off[k + 1]; ++q) gather_node_rows<E, GATHER_MAX_DEGREE>(*gex, *gsh, ga, pl.node_order[q]);
+    }
+    if (c.nchunks_out) *c.nchunks_out = pl.nchunks;
+    delete gex;
+    delete gsh;
   }
   delete ex;
   delete sh;
@@ -141,7 +176,12 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   if (!err.empty()) { std::fprintf(stderr, "c8emu: %s\n", err.c_str()); return -3; }
   int status = 0;
   Call c;
-  c.what = what;
+  c.what = what & 0xff;
+  c.staged = (what >> 8) & 1;
+  c.nnodes = nnodes;
+  c.graph = &graph;
+  c.mesh = &mesh;
+  c.nchunks_out = &g_last_nchunks;
   c.nelems = nelems;
   c.mt = MeshTables{mesh.conn.data(), mesh.coords.data(), graph.nodeptr.data(), graph.pos.data(), elem_set, nullptr, params};
   c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};

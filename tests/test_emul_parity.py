@@ -52,6 +52,30 @@ def test_adjoint_chain_wave_kernel(model, params, eps):
     check_adjoint_chain(orc, dut, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_staged_gather_assembly(model, params, eps):
+    # staged assembly: element matrices stored element-major, rows summed per node (gather_node_rows)
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.wave = dut.staged = True
+    check_forward(orc, dut, c, model, eps, TOL)
+    check_adjoint_chain(orc, dut, c, model, eps, TOL)
+
+
+def test_staged_assembly_goes_round_the_ring():
+    # a long thin brick: 16 chunks through a ring of three, node rows summed as their last chunk completes
+    import emul_lib
+    import oracle_lib as ol
+    from meshes import brick, jiggle
+    from parity_cases import J2
+    c, conn, sets = brick(2, 2, 16, 0.4, 0.4, 3.0)
+    c = jiggle(c, sets, 0.03)
+    orc, dut = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2), factory(ol.HEX8, c, conn, "small_J2", J2)
+    dut.wave = dut.staged = True
+    check_forward(orc, dut, c, "small_J2", 0.004, TOL)
+    assert emul_lib.lib().c8emu_last_nchunks() > 4
+    check_adjoint_chain(orc, dut, c, "small_J2", 0.004, TOL)
+
+
 @pytest.mark.parametrize("kind,wave", [("hex8", False), ("hex8", True), ("tet4", False)])
 def test_two_element_sets(kind, wave):
     check_two_element_sets(factory, kind, TOL, wave=wave)

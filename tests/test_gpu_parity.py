@@ -115,6 +115,49 @@ def test_adjoint_gradient_fd_check_through_gpu():
     assert np.log10(errs.max() / errs.min()) > 5.0 and errs.min() < 1e-6 * abs(gd), (errs, gd)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_staged_gather_assembly_hex8(model, params, eps):
+    # scatter mode GATHER: element matrices staged element-major, rows summed per node, no atomics
+    orc, gpu, c = make_pair(factory("gather", "wave"), "hex8", model, params)
+    check_forward(orc, gpu, c, model, eps, TOL)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+
+
+def test_staged_gather_ring_pipeline():
+    # small chunks: 20+ chunks through the ring of three, gathers overlapping later chunks on their own stream
+    from gpu_backend import GpuBackend
+    c, conn, sets = brick(3, 3, 40, 0.3, 0.3, 4.0)
+    c = jiggle(c, sets, 0.02)
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+    gpu = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather")
+    gpu.asm.set_stage_chunk(4)
+    check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
+    check_adjoint_chain(orc, gpu, c, "small_J2", 0.004, TOL)
+
+
+def test_staged_gather_two_sets_and_reproducible():
+    check_two_element_sets(factory("gather", "wave"), "hex8", TOL)
+    # two runs are bitwise identical (fixed summation order); tet4 refuses the mode loudly
+    from gpu_backend import GpuBackend
+    from parity_cases import mesh_of
+    c, conn = hex_mesh((5, 4, 3))
+    g = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather")
+    u, p = prescribed_fields(c, 0.004, ramp=True)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    out = []
+    for _ in range(2):
+        ls, xi = g.new_linsys(), g.new_state()
+        assert g.forward_jacobian(u, p, z, zp, g.new_state(), xi, ls) == 0
+        out.append(ls)
+    for i in range(2):
+        assert np.array_equal(out[0].b[i], out[1].b[i])
+        for j in range(2):
+            assert np.array_equal(out[0].A[i][j], out[1].A[i][j])
+    et, ct, connt = mesh_of("tet4")
+    with pytest.raises(RuntimeError, match="hex8"):
+        GpuBackend(et, ct, connt, "small_J2", J2, scatter="gather")
+
+
 @pytest.mark.parametrize("kind,kernel", [("hex8", "wave"), ("hex8", "slot"), ("tet4", "auto")])
 @pytest.mark.parametrize("scatter", ["colored", "atomic"])
 def test_two_element_sets(kind, kernel, scatter):
