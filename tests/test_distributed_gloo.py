@@ -141,3 +141,81 @@ def test_four_parts_gloo():
 def test_eight_analytic_brick_parts_gloo():
     # the weak-scaling partition (brick_part, no global mesh on any rank) against the global assembly
     run(8, (4, 4, 4), (2, 2, 2), use_brick_part=True)
+
+
+def adjoint_worker(rank, world, port, n, pdims, out):
+    """K3 -> C2/C1, C3, K4, K5 -> C4 on every part (SURVEY 8e 'adjoint specifics'): the histories g, f stay local,
+    z needs the owner -> ghost copy before K4/K5, the gradient is one packed all-reduce."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        import oracle_lib as ol
+        from calibr8_amd import distributed as D
+        from calibr8_amd.lib import load_library
+        c, conn, u, p = global_problem(n)
+        L = load_library()
+        ep = np.zeros(len(conn), dtype=np.int32)
+        L.c8_brick_partition(n[0], n[1], n[2], pdims[0], pdims[1], pdims[2], ep.ctypes.data_as(C.POINTER(C.c_int32)))
+        part = D.part_from_global(c, conn, ep, rank, world)
+        plan = D.HaloPlan(part, dist)
+        gid, no = plan.node_gid, part.nowned
+        active = [0, 1, 2, 3]
+        orc = ol.Oracle(ol.HEX8, c[gid], part.conn, "small_J2", J2, extra_pairs=plan.extra_pairs)
+        ref = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+        for o in (orc, ref):
+            o.set_active(0, active)
+        halo = D.Halo(plan, orc.rowptr[0][0], orc.colidx[0][0])
+        rng = np.random.default_rng(5)
+        z_u, z_p = rng.standard_normal(len(u)) * 1e-3, rng.standard_normal(len(p)) * 1e-3
+
+        def chain(o, uu, pp, zu, zp, fix_ghosts=None):
+            xi, ls = o.new_state(), o.new_linsys()
+            assert o.forward_jacobian(uu, pp, 0 * uu, 0 * pp, o.new_state(), xi, o.new_linsys()) == 0
+            g = np.zeros((o.nelems, o.npts, o.nloc))
+            f = np.zeros((o.nelems, o.npts, 4 * o.nn))
+            o.adjoint_jacobian(uu, pp, 0 * uu, 0 * pp, o.new_state(), xi, g, f, ls)
+            if fix_ghosts is not None:
+                zu, zp = fix_ghosts(zu, zp)
+            phi = np.zeros_like(g)
+            o.solve_adjoint_local(uu, pp, 0 * uu, 0 * pp, o.new_state(), xi, zu, zp, phi, g, f)
+            grad = o.qoi_gradient(uu, pp, 0 * uu, 0 * pp, o.new_state(), xi, zu, zp, phi, len(active))
+            return ls, grad
+
+        def c3(zu, zp):  # ghost copies are stale until the owner -> ghost exchange
+            x = [torch.from_numpy(zu.copy()), torch.from_numpy(zp.copy())]
+            x[0][no * 3: part.ntouched * 3] = 99.0
+            x[1][no: part.ntouched] = 99.0
+            halo.scatter_x(x)
+            return x[0].numpy(), x[1].numpy()
+
+        lu = np.ascontiguousarray(u.reshape(-1, 3)[gid].ravel())
+        lp = np.ascontiguousarray(p[gid])
+        lzu = np.ascontiguousarray(z_u.reshape(-1, 3)[gid].ravel())
+        lzp = np.ascontiguousarray(z_p[gid])
+        ls, grad = chain(orc, lu, lp, lzu, lzp, fix_ghosts=c3)
+        lr, grad_ref = chain(ref, u, p, z_u, z_p)
+        # C1 on the adjoint right-hand side; the transposed Jacobian goes through the same C2 as in the forward test
+        b = [torch.from_numpy(ls.b[i]) for i in range(2)]
+        halo.gather_b(b)
+        worst = 0.0
+        for i in range(2):
+            bo = b[i].numpy()[: no * NEQ[i]].reshape(no, NEQ[i])
+            br = lr.b[i].reshape(-1, NEQ[i])[gid[:no]]
+            worst = max(worst, np.abs(bo - br).max() / np.abs(lr.b[i]).max())
+        gt = torch.from_numpy(grad.copy())
+        halo.allreduce(gt)  # C4
+        gerr = np.abs(gt.numpy() - grad_ref).max() / np.abs(grad_ref).max()
+        out[rank] = (worst, gerr)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_parts_adjoint_chain_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(adjoint_worker, args=(2, free_port(), (6, 4, 4), (2, 1, 1), out), nprocs=2, join=True)
+    assert len(out) == 2
+    for r in range(2):
+        worst, gerr = out[r]
+        assert worst < 1e-13 and gerr < 1e-12, (r, worst, gerr)
