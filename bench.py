@@ -192,8 +192,9 @@ def main():
                            "traffic": measured_traffic(n, args.scatter, "slot" if args.kernel == "slot" else "wave"),
                            "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
                            "kernel": ("k_forward_jacobian" if args.kernel == "slot" else "k_forward_jacobian_wave") +
-                                     "<hex8,small_J2> (%d launches per step)"
-                                     % (asm.ncolors if args.scatter == "colored" else 1)}
+                                     ("<hex8,small_J2> into the element stage + k_gather_rows, per chunk of elements"
+                                      if args.scatter == "gather" else "<hex8,small_J2> (%d launches per step)"
+                                      % (asm.ncolors if args.scatter == "colored" else 1))}
         if not args.no_cpu and world == 1:
             try:
                 avail = len(os.sched_getaffinity(0))
