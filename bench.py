@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
     ap.add_argument("--stage-chunk", type=int, default=0, help="scatter=gather: minimum elements per staged chunk")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the ghost rows after the whole assembly")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on one GPU (halo staged through the host)")
@@ -125,12 +126,37 @@ def main():
     ls = asm.new_linsys()
     asm.set_async(True)
 
-    def step():
-        # eval_forward_jacobian, then la->gather_A / gather_b (primal.cpp:99,110-111)
-        asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
-        if world > 1:
-            halo.gather_b(ls.b)
-            halo.gather_A(ls.A)
+    overlap = world > 1 and args.scatter == "atomic" and not args.no_overlap
+    if overlap:
+        e_if = torch.as_tensor(plan.interface_elems, device=dev)
+        e_in = torch.as_tensor(plan.interior_elems, device=dev)
+
+    def step(ev=None):
+        """eval_forward_jacobian, then la->gather_A / gather_b (primal.cpp:99,110-111).  With more than one rank
+        the elements that add into ghost rows are assembled first and the exchange of those rows (one grouped
+        all_to_all) runs while the interior elements are assembled; `ev` = HIP-event pairs around the assembly
+        launches."""
+        if not overlap:
+            if ev:
+                ev[0][0].record()
+            asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+            if ev:
+                ev[0][1].record()
+            if world > 1:
+                halo.finish_gather(ls, halo.start_gather(ls))
+            return
+        if ev:
+            ev[0][0].record()
+        asm.forward_jacobian_subset(u, p, u0, p0, xi_prev, xi, ls, e_if)
+        if ev:
+            ev[0][1].record()
+        h = halo.start_gather(ls)
+        if ev:
+            ev[1][0].record()
+        asm.forward_jacobian_subset(u, p, u0, p0, xi_prev, xi, ls, e_in)
+        if ev:
+            ev[1][1].record()
+        halo.finish_gather(ls, h)
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,25 +167,42 @@ def main():
     for _ in range(args.warmup):
         step()
     assert asm.status() == 0
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    E = lambda: torch.cuda.Event(enable_timing=True)
+    ev = [[(E(), E()), (E(), E())] for _ in range(args.steps)]  # HIP events on the stream the kernels are launched on
     barrier()
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()  # HIP events on the stream the kernels are launched on: assembly kernels only
-        asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
-        b.record()
-        if world > 1:
-            halo.gather_b(ls.b)
-            halo.gather_A(ls.A)
+    for pairs in ev:
+        step(pairs)
     barrier()
     dt = time.perf_counter() - t0
     assert asm.status() == 0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    # assembly kernels only (both launches of a step when the exchange is overlapped)
+    kernel_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in pairs[:2 if overlap else 1]) for pairs in ev]))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    overlap_check = None
+    if overlap:  # untimed: the overlapped step against the blocking exchange after a whole assembly
+        ls.zero()
+        step()
+        ref_flat = ls.flat.clone()
+        ls.zero()
+        asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+        halo.finish_gather(ls, halo.start_gather(ls))
+        no = part.nowned  # owned rows only: ghost rows are scratch after the exchange
+        d = 0.0
+        for k, neq in ((4, 3), (5, 1)):
+            lo = int(ls.offsets[k])
+            d = max(d, float((ls.flat[lo:lo + no * neq] - ref_flat[lo:lo + no * neq]).abs().max() /
+                             ls.flat[lo:lo + no * neq].abs().max()))
+        lo, hi = 0, int(asm.rowptr[0][0][no * 3])
+        d = max(d, float((ls.flat[lo:hi] - ref_flat[lo:hi]).abs().max() / ls.flat[lo:hi].abs().max()))
+        chk = torch.tensor([d], dtype=torch.float64, device=tmax.device)
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+        overlap_check = float(chk.item())
+        assert overlap_check < 1e-12, overlap_check
     hb = torch.tensor([float(halo.bytes_per_gather_A + halo.bytes_per_gather_b) if world > 1 else 0.0],
                       dtype=torch.float64, device=tmax.device)
     if world > 1:
@@ -181,7 +224,9 @@ def main():
                    "colors": asm.ncolors, "part_grid": list(pdims),
                    "parallelism": "one n^3 element block per GPU; ghost rows of A and b ADDed into their owners "
                                   "by one grouped neighbour all_to_all (RCCL) per step",
-                   "halo_send_bytes_per_step_max_rank": halo_bytes},
+                   "halo_send_bytes_per_step_max_rank": halo_bytes,
+                   "halo_overlapped_with_interior_assembly": bool(overlap),
+                   "overlap_vs_blocking_max_rel_diff": overlap_check},
     }
     if rank == 0:
         nnz_total = sum(asm.nnz[i][j] for i in range(2) for j in range(2))

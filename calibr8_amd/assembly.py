@@ -37,15 +37,17 @@ class LinearSystem:
 
     def __init__(self, asm):
         import torch
-        self.A = [[torch.zeros(asm.nnz[i][j], dtype=torch.float64, device=asm.device) for j in range(2)]
-                  for i in range(2)]
-        self.b = [torch.zeros(asm.nnodes * NEQ[i], dtype=torch.float64, device=asm.device) for i in range(2)]
+        # one allocation, the six arrays are views of it: zero_all is one fill and the halo exchange packs and
+        # unpacks all of them with one gather / one index_add (distributed.Halo.start_gather)
+        sizes = [asm.nnz[i][j] for i in range(2) for j in range(2)] + [asm.nnodes * NEQ[i] for i in range(2)]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)  # A00 A01 A10 A11 b0 b1
+        self.flat = torch.zeros(int(self.offsets[-1]), dtype=torch.float64, device=asm.device)
+        v = [self.flat[int(self.offsets[k]):int(self.offsets[k + 1])] for k in range(6)]
+        self.A = [[v[0], v[1]], [v[2], v[3]]]
+        self.b = [v[4], v[5]]
 
     def zero(self):  # la->zero_all(), primal.cpp:98
-        for i in range(2):
-            self.b[i].zero_()
-            for j in range(2):
-                self.A[i][j].zero_()
+        self.flat.zero_()
 
     def c_struct(self):
         s = _l.System()
@@ -190,6 +192,12 @@ class Assembler:
         """eval_forward_jacobian: returns 0, or -1 if a local Newton solve failed."""
         st, sy = self._state(u, p, u_prev, p_prev, xi_prev, xi), ls.c_struct()
         return self._rc(self.L.c8_assemble_forward_jacobian(self.h, C.byref(st), C.byref(sy)))
+
+    def forward_jacobian_subset(self, u, p, u_prev, p_prev, xi_prev, xi, ls, elems):
+        """eval_forward_jacobian over the elements listed in `elems` (int32 device tensor), atomic adds."""
+        st, sy = self._state(u, p, u_prev, p_prev, xi_prev, xi), ls.c_struct()
+        return self._rc(self.L.c8_assemble_forward_jacobian_subset(self.h, C.byref(st), C.byref(sy),
+                                                                    C.c_void_p(elems.data_ptr()), int(elems.numel())))
 
     def global_residual(self, u, p, u_prev, p_prev, xi_prev, xi, ls):
         st, sy = self._state(u, p, u_prev, p_prev, xi_prev, xi), ls.c_struct()

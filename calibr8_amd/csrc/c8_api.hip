@@ -290,6 +290,8 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
   if (!c->d_stamps) C8_HIP(hipMalloc((void**)&c->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
   sa.stamps = c->d_stamps;
 #endif
+  if (c->subset && scatters && c->scatter_mode != C8_SCATTER_ATOMIC)
+    return fail(C8_ERR_ARG, std::string(what) + ": element subsets need C8_SCATTER_ATOMIC");
   // staged assembly: the two Jacobian assemblies through their wave kernels; everything else (residual-only
   // assembly: 32 adds per element) keeps atomic adds
   bool const staged = scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] &&
@@ -298,7 +300,11 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly needs the wave-per-element kernels");
   if (staged) return run_staged(c, fn, fa, aa, sa);
   LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
-  if (colored) {
+  if (c->subset) {
+    a.mt.order = c->subset;
+    a.count = c->subset_count;
+    C8_HIP(fn(a));
+  } else if (colored) {
     int const nc = (int)c->color_off.size() - 1;
     for (int k = 0; k < nc; ++k) {
       a.first = c->color_off[k];
@@ -334,6 +340,17 @@ int c8_assemble_forward_jacobian(c8_ctx* c, const c8_state* st, const c8_system*
   LaunchFn fn = c->ks.forward_jacobian;
   if (c->ks.forward_jacobian_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.forward_jacobian_wave;
   return run(c, fn, field_args(st), AdjointArgs{}, sa, true, "c8_assemble_forward_jacobian");
+}
+
+int c8_assemble_forward_jacobian_subset(c8_ctx* c, const c8_state* st, const c8_system* sys, const int32_t* elems, int count) {
+  if (!c || count < 0 || (count > 0 && !elems)) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian_subset: bad argument");
+  if (count == 0) return C8_OK;
+  c->subset = elems;
+  c->subset_count = count;
+  int const rc = c8_assemble_forward_jacobian(c, st, sys);
+  c->subset = nullptr;
+  c->subset_count = 0;
+  return rc;
 }
 
 int c8_assemble_residual(c8_ctx* c, const c8_state* st, const c8_system* sys) {

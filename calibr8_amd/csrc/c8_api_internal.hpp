@@ -48,5 +48,7 @@ struct c8_ctx {
   int scatter_mode = C8_SCATTER_COLORED;
   int kernel_variant = C8_KERNEL_AUTO;
   int async = 0;
+  int32_t const* subset = nullptr;   // set for the duration of a *_subset call
+  int subset_count = 0;
 };
 

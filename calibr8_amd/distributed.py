@@ -124,6 +124,11 @@ class HaloPlan:
         # element adjacency of ghost rows only (gids, in ascending LOCAL id order = the row order of the graph)
         ghost_lo = p.nowned
         touching = np.nonzero((p.conn >= ghost_lo).any(axis=1))[0]
+        # elements that add into ghost rows: assembled first, so that the exchange can overlap the rest
+        self.interface_elems = touching.astype(np.int32)
+        mask = np.ones(len(p.conn), dtype=bool)
+        mask[touching] = False
+        self.interior_elems = np.nonzero(mask)[0].astype(np.int32)
         rows = np.repeat(p.conn[touching], nn, axis=1).reshape(-1)          # row node of every (a, b) pair
         cols = np.tile(p.conn[touching], (1, nn)).reshape(-1)
         keep = rows >= ghost_lo
@@ -272,6 +277,54 @@ class Halo:
             for q in range(nblk):
                 out[q][r] = parts[q]
         return out
+
+    # ---- C1 + C2 as ONE exchange that overlaps the assembly of the interior elements ----------------------
+    def flat_tables(self, offsets):
+        """Index tables into a LinearSystem.flat laid out as A00 A01 A10 A11 b0 b1 (`offsets` = its 7 offsets):
+        send indices in rank-major order (chunk r = everything rank r receives from me) and the matching
+        receive indices."""
+        t, W = self.torch, range(self.world)
+        off = [int(o) for o in offsets]
+        blocks = [(i, j) for i in range(2) for j in range(2)]
+        send, recv = [], []
+        self._flat_in, self._flat_out = [], []
+        for r in W:
+            s_r = [self.A_send[i][j][r] + off[q] for q, (i, j) in enumerate(blocks)] + [self.b_send[i][r] + off[4 + i] for i in range(2)]
+            r_r = [self.A_recv[i][j][r] + off[q] for q, (i, j) in enumerate(blocks)] + [self.b_recv[i][r] + off[4 + i] for i in range(2)]
+            send.append(t.cat(s_r))
+            recv.append(t.cat(r_r))
+            self._flat_in.append(int(send[-1].numel()))
+            self._flat_out.append(int(recv[-1].numel()))
+        self._flat_send, self._flat_recv = t.cat(send), t.cat(recv)
+
+    def start_gather(self, ls):
+        """Pack the ghost rows of A and b (one gather) and start the exchange; returns a handle.  Everything
+        that adds into ghost rows must have been enqueued before; work enqueued after this call (the assembly
+        of the interior elements, which only touches owned rows) runs while the exchange is in flight."""
+        if self.world == 1:
+            return None
+        t = self.torch
+        if not hasattr(self, "_flat_send"):
+            self.flat_tables(ls.offsets)
+        sbuf = ls.flat[self._flat_send]
+        if sbuf.is_cuda and self.dist.get_backend() == "gloo":  # rehearsal: several ranks on one GPU, via the host
+            sh = sbuf.cpu()
+            rbuf = t.empty(sum(self._flat_out), dtype=sbuf.dtype)
+            work = self.dist.all_to_all_single(rbuf, sh, self._flat_out, self._flat_in, async_op=True)
+            return (work, rbuf, sh)
+        rbuf = t.empty(sum(self._flat_out), dtype=sbuf.dtype, device=sbuf.device)
+        work = self.dist.all_to_all_single(rbuf, sbuf, self._flat_out, self._flat_in, async_op=True)
+        return (work, rbuf, sbuf)
+
+    def finish_gather(self, ls, handle):
+        """Wait for the exchange and ADD the received ghost contributions into the owned rows (one index_add;
+        atomic adds, so it may run while other kernels still add into the same rows)."""
+        if handle is None:
+            return ls
+        work, rbuf, _keep = handle
+        work.wait()
+        ls.flat.index_add_(0, self._flat_recv, rbuf.to(ls.flat.device))
+        return ls
 
     def scatter_x(self, x):
         """C3, in place: owner values of a nodal field pair x = [u, p] copied to the ghost copies."""

@@ -80,6 +80,7 @@ SYMBOLS = [
     ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_status", C.c_int, [C.c_void_p]),
     ("c8_assemble_forward_jacobian", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),
+    ("c8_assemble_forward_jacobian_subset", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System), C.c_void_p, C.c_int]),
     ("c8_assemble_residual", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),
     ("c8_assemble_adjoint_jacobian", C.c_int, [C.c_void_p, C.POINTER(State), C.c_void_p, C.c_void_p, C.POINTER(System)]),
     ("c8_solve_adjoint_local", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),

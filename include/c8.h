@@ -131,6 +131,10 @@ int c8_status(c8_ctx* ctx);
 /* eval_forward_jacobian (evaluations.cpp:12-154): R and dR/dx with the local state condensed;
  * writes the converged local state to st->xi. */
 int c8_assemble_forward_jacobian(c8_ctx* ctx, const c8_state* st, const c8_system* sys);
+/* The same over a subset of the elements (`elems`: DEVICE array of `count` distinct element ids), with atomic
+ * adds.  For overlapping the halo exchange with the assembly: assemble the elements that touch
+ * ghost nodes, start the exchange, assemble the rest.  The context must be in C8_SCATTER_ATOMIC mode. */
+int c8_assemble_forward_jacobian_subset(c8_ctx* ctx, const c8_state* st, const c8_system* sys, const int32_t* elems, int count);
 /* eval_global_residual (evaluations.cpp:156-259): R only, from the stored local state. */
 int c8_assemble_residual(c8_ctx* ctx, const c8_state* st, const c8_system* sys);
 /* eval_adjoint_jacobian (evaluations.cpp:349-526), QoI = "average displacement":

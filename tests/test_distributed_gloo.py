@@ -69,10 +69,26 @@ def worker(rank, world, port, n, pdims, use_brick_part, out):
         lp = np.ascontiguousarray(p[gid])
         ls, xi = orc.new_linsys(), orc.new_state()
         assert orc.forward_jacobian(lu, lp, 0 * lu, 0 * lp, orc.new_state(), xi, ls) == 0
+        # the overlapped form first (it must not see the in-place result of the blocking form): one flat
+        # array A00 A01 A10 A11 b0 b1, one exchange started before / finished after other work
+        class FlatLS:
+            pass
+        fl = FlatLS()
+        parts = [ls.A[0][0], ls.A[0][1], ls.A[1][0], ls.A[1][1], ls.b[0], ls.b[1]]
+        fl.offsets = np.concatenate([[0], np.cumsum([len(q) for q in parts])]).astype(np.int64)
+        fl.flat = torch.from_numpy(np.concatenate(parts).copy())
+        h = halo.start_gather(fl)
+        busy = torch.ones(1000).sum()  # stands for the interior assembly
+        halo.finish_gather(fl, h)
+        assert set(plan.interface_elems) | set(plan.interior_elems) == set(range(len(part.conn)))
+        assert not (set(plan.interface_elems) & set(plan.interior_elems))
+        assert (part.conn[plan.interior_elems] < part.nowned).all()
         A = [[torch.from_numpy(ls.A[i][j]) for j in range(2)] for i in range(2)]
         b = [torch.from_numpy(ls.b[i]) for i in range(2)]
         halo.gather_A(A)
         halo.gather_b(b)
+        flat_ref = np.concatenate([A[0][0].numpy(), A[0][1].numpy(), A[1][0].numpy(), A[1][1].numpy(), b[0].numpy(), b[1].numpy()])
+        assert np.abs(fl.flat.numpy() - flat_ref).max() <= 1e-13 * np.abs(flat_ref).max()
         # reference: single-part assembly of the whole mesh
         ref = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
         lr, xr = ref.new_linsys(), ref.new_state()
