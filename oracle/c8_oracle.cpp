@@ -36,6 +36,7 @@
 #include <string>
 #include <thread>
 #include <type_traits>
+#include <set>
 #include <vector>
 
 namespace c8o {
@@ -1058,6 +1059,17 @@ struct Ctx {
   Local<Fad>* local_f = nullptr;
   int nloc = 0;
   int ngpts = 0;  // coupled points per element = points of the local-state field
+  // QoI: 0 = average displacement (avg_disp.cpp), 1 = calibration (calibration.cpp, 3-D form)
+  int qoi_kind = 0;
+  struct Calib {
+    double balance = 0., weights[3] = {1., 1., 1.}, area = 0., dt_over_T = 1.;
+    int comp = 0;                            // reaction force component
+    std::vector<int> nf;                     // [nelems] nodes of the element's face on the displacement side set (0 = none)
+    std::vector<int> fnodes;                 // [nelems][4] local node ids of that face (m_mapping_disp -> downward face)
+    std::vector<unsigned> load_mask;         // [nelems] bit n set: local node n lies on the load plane (m_mapping_load)
+    std::vector<double> u_meas;              // measured displacement of the current step, nodal [nnodes][3]
+    double load_meas = 0., total_load = 0., load_mismatch = 0.;
+  } cal;
   ~Ctx() { delete local_d; delete local_f; }
 };
 
@@ -1270,6 +1282,111 @@ template <class T> static T avg_disp_point(Global<T> const& g, double w, double 
 }
 static double dxq(Fad const& v, int j) { return v.dx(j); }
 
+// ---- Calibration QoI, 3-D form (calibration.cpp) ------------------------------------------------------------
+// Element faces in local node ids (this restatement's own numbering of the downward faces; the reference only
+// uses the face to find its nodes).
+static int const TET_FACES[4][3] = {{0, 1, 2}, {0, 1, 3}, {1, 2, 3}, {0, 2, 3}};
+static int const HEX_FACES[6][4] = {{0, 1, 2, 3}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
+
+// face quadrature of order 2 (calibration.cpp:262-266): tri3 3-point rule, quad4 2x2 Gauss.  Returns the number of
+// points; Nf = face shape functions, wdv = weight * getDV of the face at the point.
+static int face_rule(int nf, double const X[][3], double Nf[][4], double* wdv) {
+  auto cross_norm = [](double const a[3], double const b[3]) {
+    double const c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
+    return std::sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+  };
+  if (nf == 3) {
+    double a[3], b[3];
+    for (int d = 0; d < 3; ++d) { a[d] = X[1][d] - X[0][d]; b[d] = X[2][d] - X[0][d]; }
+    double const dv = cross_norm(a, b);
+    double const st[3][2] = {{1. / 6., 1. / 6.}, {2. / 3., 1. / 6.}, {1. / 6., 2. / 3.}};
+    for (int q = 0; q < 3; ++q) {
+      Nf[q][0] = 1. - st[q][0] - st[q][1]; Nf[q][1] = st[q][0]; Nf[q][2] = st[q][1]; Nf[q][3] = 0.;
+      wdv[q] = dv / 6.;
+    }
+    return 3;
+  }
+  double const gp = 1. / std::sqrt(3.);
+  int q = 0;
+  for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i, ++q) {
+      double const s = (i ? gp : -gp), t = (j ? gp : -gp);
+      double const sn[4] = {-1., 1., 1., -1.}, tn[4] = {-1., -1., 1., 1.};
+      double ds[3] = {0., 0., 0.}, dt[3] = {0., 0., 0.};
+      for (int k = 0; k < 4; ++k) {
+        Nf[q][k] = 0.25 * (1. + sn[k] * s) * (1. + tn[k] * t);
+        for (int d = 0; d < 3; ++d) {
+          ds[d] += 0.25 * sn[k] * (1. + tn[k] * t) * X[k][d];
+          dt[d] += 0.25 * tn[k] * (1. + sn[k] * s) * X[k][d];
+        }
+      }
+      wdv[q] = cross_norm(ds, dt);
+    }
+  return 4;
+}
+// area of a face by the one-point rule the reference uses (calibration.cpp:122-126)
+static double face_area(int nf, double const X[][3]) {
+  double Nf[4][4], wdv[4];
+  if (nf == 3) { face_rule(3, X, Nf, wdv); return 3. * wdv[0]; }
+  double ds[3] = {0., 0., 0.}, dt[3] = {0., 0., 0.};
+  double const sn[4] = {-1., 1., 1., -1.}, tn[4] = {-1., -1., 1., 1.};
+  for (int k = 0; k < 4; ++k) for (int d = 0; d < 3; ++d) { ds[d] += 0.25 * sn[k] * X[k][d]; dt[d] += 0.25 * tn[k] * X[k][d]; }
+  double const c0 = ds[1] * dt[2] - ds[2] * dt[1], c1 = ds[2] * dt[0] - ds[0] * dt[2], c2 = ds[0] * dt[1] - ds[1] * dt[0];
+  return 4. * std::sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+}
+
+// compute_surface_mismatch (calibration.cpp:225-300).  At a face point only the face's nodes have non-zero shape
+// functions, and there they equal the face's own shape functions, so global->interpolate(boundaryToElementXi(..))
+// is the face interpolation of the nodal values.
+template <class T> static T calib_surface(Ctx const& c, Global<T> const& g, int e) {
+  auto const& cal = c.cal;
+  int const nf = cal.nf[e], nn = c.kit.nn;
+  int const* fn = &cal.fnodes[(size_t)e * 4];
+  double X[4][3], Nf[4][4], wdv[4];
+  for (int k = 0; k < nf; ++k)
+    for (int d = 0; d < 3; ++d) X[k][d] = c.coords[(size_t)c.conn[e * nn + fn[k]] * 3 + d];
+  int const nq = face_rule(nf, X, Nf, wdv);
+  T mismatch = 0.;
+  for (int q = 0; q < nq; ++q) {
+    T qoi = 0.;
+    for (int d = 0; d < 3; ++d) {
+      T u_fem = 0.;
+      double u_meas = 0.;
+      for (int k = 0; k < nf; ++k) {
+        u_fem += g.x_nodal[0][fn[k]][d] * Nf[q][k];
+        u_meas += cal.u_meas[(size_t)c.conn[e * nn + fn[k]] * 3 + d] * Nf[q][k];
+      }
+      qoi += cal.weights[d] * (u_fem - u_meas) * (u_fem - u_meas);
+    }
+    mismatch += 0.5 * qoi * wdv[q] / cal.area * cal.dt_over_T;
+  }
+  return mismatch;
+}
+// compute_load (calibration.cpp:302-343): the internal force of the coupled weak form at this point, summed
+// over the element's nodes on the load plane
+template <class T> static T calib_load(Ctx const& c, Global<T>& g, Local<T>& local, int e, double w, double dv) {
+  g.zero_residual();
+  g.evaluate(local, w, dv, 0);
+  T load = 0.;
+  for (int n = 0; n < c.kit.nn; ++n)
+    if (c.cal.load_mask[e] & (1u << n)) load += g.R_nodal[0][n][c.cal.comp];
+  g.zero_residual();
+  return load;
+}
+// QoI<T>::evaluate at one coupled point: AvgDisp (avg_disp.cpp:16-33) or Calibration (calibration.cpp:418-480:
+// the double instantiation has the displacement term only, the FADT one adds balance*dt/T*load_mismatch*load)
+static double qoi_point(Ctx& c, Global<double>& g, Local<double>&, int e, double w, double dv) {
+  if (c.qoi_kind == 0) return avg_disp_point(g, w, dv);
+  return c.cal.nf[e] ? calib_surface(c, g, e) : 0.;
+}
+static Fad qoi_point(Ctx& c, Global<Fad>& g, Local<Fad>& local, int e, double w, double dv) {
+  if (c.qoi_kind == 0) return avg_disp_point(g, w, dv);
+  Fad v = 0.;
+  if (c.cal.nf[e]) v += calib_surface(c, g, e);
+  if (c.cal.load_mask[e]) v += c.cal.balance * c.cal.dt_over_T * c.cal.load_mismatch * calib_load(c, g, local, e, w, dv);
+  return v;
+}
+
 // eval_adjoint_jacobian, evaluations.cpp:349-526 (QoI = average displacement)
 static void adjoint_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, double* g_hist, double const* f_hist,
                              LinSys& ls) {
@@ -1314,13 +1431,13 @@ static void adjoint_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, double*
             scatter_lhs(c, global, e, dtotalT.data(), nd, ls);
             local.unseed_wrt_xi();
             // dJ/dx with x seeded, xi plain (:469-471)
-            Fad J = avg_disp_point(global, w, dv);
+            Fad J = qoi_point(c, global, local, e, w, dv);
             for (int j = 0; j < nd; ++j) dJ_dx[j] = dxq(J, j);
             global.unseed_wrt_x();
             // dJ/dxi with xi seeded (:474-478)
             nderivs = local.seed_wrt_xi();
             global.interpolate();
-            J = avg_disp_point(global, w, dv);
+            J = qoi_point(c, global, local, e, w, dv);
             for (int j = 0; j < nl; ++j) dJ_dxi[j] = dxq(J, j);
             local.unseed_wrt_xi();
             double* g_pt = &g_hist[qp * nl];
@@ -1435,11 +1552,45 @@ static double eval_qoi(Ctx& c, Local<double>& local, Fields const& f) {
         double const dv = shape_global(c.kit.type, nn, X, c.kit.pts[0][pt], N, dN);
         global.set_weights(N, dN);
         global.interpolate();
-        J += avg_disp_point(global, w, dv);
+        J += qoi_point(c, global, local, e, w, dv);
       }
     }
-  (void)local;
+  if (c.qoi_kind == 1)  // Calibration::postprocess (calibration.cpp:374-381), one rank
+    J += 0.5 * c.cal.balance * c.cal.dt_over_T * c.cal.load_mismatch * c.cal.load_mismatch;
   return J;
+}
+
+// preprocess_qoi (evaluations.cpp:262-347) + Calibration::preprocess / preprocess_finalize (calibration.cpp:345-372,
+// 398-416): the total reaction load of the step and its mismatch with the measured load
+static double qoi_preprocess(Ctx& c, Local<double>& local, Fields const& f) {
+  if (c.qoi_kind != 1) return 0.;
+  Global<double> global;
+  global.stab_mult = c.stab_mult;
+  global.before_elems(c.kit.nn);
+  int const nn = c.kit.nn, nl = local.ndofs;
+  double total = 0.;
+  for (int es = 0; es < c.nsets; ++es) {
+    local.before_elems(&c.params[(size_t)es * c.nparams], c.nparams);
+    for (int e : c.set_elems[es]) {
+      if (!c.cal.load_mask[e]) continue;
+      double X[8][3], N[8], dN[8][3];
+      elem_coords(c, e, X);
+      global.h = elem_size(c, X);
+      global.gather(f.u, f.p, f.u_prev, f.p_prev, &c.conn[e * nn]);
+      for (int pt = 0; pt < c.kit.npts[0]; ++pt) {
+        double const w = c.kit.wts[0][pt];
+        double const dv = shape_global(c.kit.type, nn, X, c.kit.pts[0][pt], N, dN);
+        global.set_weights(N, dN);
+        global.interpolate();
+        size_t const qp = (size_t)e * c.ngpts + pt;
+        local.gather(&f.xi[qp * nl], &f.xi_prev[qp * nl]);
+        total += calib_load(c, global, local, e, w, dv);
+      }
+    }
+  }
+  c.cal.total_load = total;
+  c.cal.load_mismatch = total - c.cal.load_meas;
+  return total;
 }
 
 // eval_qoi_gradient, evaluations.cpp:758-925 (no DFAD/NN parameters)
@@ -1483,7 +1634,7 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
               for (int k = 0; k < nl; ++k) s += dC[k * nderivs + a] * phi[qp * nl + k];
               es_grad[a] += s;
             }
-            Fad const J = avg_disp_point(global, w, dv);
+            Fad const J = qoi_point(c, global, local, e, w, dv);
             for (int a = 0; a < nact; ++a) es_grad[a] += dxq(J, a);
           }
           global.zero_residual();
@@ -1559,6 +1710,66 @@ int c8o_npts(void* h) { return ((Ctx*)h)->ngpts; }
 void c8o_set_params(void* h, double const* params) {
   Ctx* c = (Ctx*)h;
   c->params.assign(params, params + (size_t)c->nsets * c->nparams);
+}
+// Calibration QoI (calibration.cpp:13-50 parameters; :55-160 before_elems).  faces: [nfaces][npf] global node ids
+// of the displacement side set; load plane: nodes with |x[coord_idx] - coord_value| < coord_tol (qoi.cpp:160-198).
+void c8o_set_calibration(void* h, int nfaces, int npf, int const* faces, double const* weights, double balance,
+                         int coord_idx, double coord_value, double coord_tol, int comp, double dt_over_T) {
+  Ctx* c = (Ctx*)h;
+  auto& cal = c->cal;
+  c->qoi_kind = 1;
+  cal.balance = balance;
+  for (int d = 0; d < 3; ++d) cal.weights[d] = weights ? weights[d] : 1.;
+  cal.comp = comp;
+  cal.dt_over_T = dt_over_T;
+  int const nn = c->kit.nn;
+  std::set<std::vector<int>> side;
+  for (int f = 0; f < nfaces; ++f) {
+    std::vector<int> key(faces + (size_t)f * npf, faces + (size_t)(f + 1) * npf);
+    std::sort(key.begin(), key.end());
+    side.insert(key);
+  }
+  cal.nf.assign(c->nelems, 0);
+  cal.fnodes.assign((size_t)c->nelems * 4, 0);
+  cal.load_mask.assign(c->nelems, 0u);
+  cal.area = 0.;
+  int const nfe = (nn == 4) ? 4 : 6, nfn = (nn == 4) ? 3 : 4;
+  for (int e = 0; e < c->nelems; ++e) {
+    for (int d = 0; d < nfe; ++d) {  // downward faces; a later match overwrites an earlier one (:107-131)
+      int const* loc = (nn == 4) ? TET_FACES[d] : HEX_FACES[d];
+      std::vector<int> key(nfn);
+      for (int k = 0; k < nfn; ++k) key[k] = c->conn[e * nn + loc[k]];
+      std::sort(key.begin(), key.end());
+      if (side.count(key)) {
+        cal.nf[e] = nfn;
+        double X[4][3];
+        for (int k = 0; k < nfn; ++k) {
+          cal.fnodes[(size_t)e * 4 + k] = loc[k];
+          for (int q = 0; q < 3; ++q) X[k][q] = c->coords[(size_t)c->conn[e * nn + loc[k]] * 3 + q];
+        }
+        cal.area += face_area(nfn, X);  // every match adds its area, as the reference does
+      }
+    }
+    for (int n = 0; n < nn; ++n)
+      if (std::abs(c->coords[(size_t)c->conn[e * nn + n] * 3 + coord_idx] - coord_value) < coord_tol) cal.load_mask[e] |= 1u << n;
+  }
+  cal.u_meas.assign((size_t)c->nnodes * 3, 0.);
+}
+void c8o_set_avg_disp(void* h) { ((Ctx*)h)->qoi_kind = 0; }
+// measured data of the current step: nodal displacements ("measured_<step>" field) and the load (load input file)
+void c8o_set_measured(void* h, double const* u_meas, double load_meas) {
+  Ctx* c = (Ctx*)h;
+  c->cal.u_meas.assign(u_meas, u_meas + (size_t)c->nnodes * 3);
+  c->cal.load_meas = load_meas;
+}
+// preprocess_qoi for the current step: returns the total reaction load; out = {area, total load, load mismatch}
+double c8o_qoi_preprocess(void* h, double const* u, double const* p, double const* u_prev, double const* p_prev,
+                          double const* xi_prev, double const* xi, double* out) {
+  Ctx* c = (Ctx*)h;
+  Fields f{u, p, u_prev, p_prev, xi_prev, const_cast<double*>(xi)};
+  double const t = qoi_preprocess(*c, *c->local_d, f);
+  if (out) { out[0] = c->cal.area; out[1] = c->cal.total_load; out[2] = c->cal.load_mismatch; }
+  return t;
 }
 void c8o_set_active(void* h, int es, int nactive, int const* idx) {
   Ctx* c = (Ctx*)h;

@@ -131,6 +131,7 @@ class Primal:
         self.xi = [be.new_state()]
         self.ls = be.new_linsys()
         self.newton_iters = []
+        self.measured = None  # Calibration QoI: ([u_meas per step], [load_meas per step]), index 0 unused
 
     def _assemble(self, step, x, xi):
         be, ls = self.be, self.ls
@@ -198,9 +199,19 @@ class Primal:
             self.solve_at_step(s)
         return self
 
+    def begin_qoi_step(self, s):
+        """measured data of the step + preprocess_qoi (adjoint_objective.cpp:33-35, :86-88) for QoIs that need it"""
+        if getattr(self, "measured", None) is not None:
+            self.be.set_measured(self.measured[0][s], self.measured[1][s])
+            self.be.qoi_preprocess(self.u[s], self.p[s], self.u[s - 1], self.p[s - 1], self.xi[s - 1], self.xi[s])
+
     def qoi(self):
         """sum over steps of eval_qoi (adjoint_objective.cpp:36-37; main_primal.cpp sums steps too)."""
-        return sum(self.be.eval_qoi(self.u[s], self.p[s]) for s in range(1, len(self.u)))
+        J = 0.0
+        for s in range(1, len(self.u)):
+            self.begin_qoi_step(s)
+            J += self.be.eval_qoi(self.u[s], self.p[s])
+        return J
 
 
 def adjoint_gradient(primal, nparams):
@@ -216,6 +227,7 @@ def adjoint_gradient(primal, nparams):
     for step in range(nsteps, 0, -1):
         u, p, xi = primal.u[step], primal.p[step], primal.xi[step]
         up, pp, xip = primal.u[step - 1], primal.p[step - 1], primal.xi[step - 1]
+        primal.begin_qoi_step(step)
         ls.zero()
         be.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, ls)
         z = [np.zeros(n3), np.zeros(be.nnodes)]

@@ -57,6 +57,12 @@ def lib():
         L.c8o_eval_qoi.restype = C.c_double
         L.c8o_eval_qoi.argtypes = [C.c_void_p, dp, dp]
         L.c8o_qoi_gradient.argtypes = [C.c_void_p] + [dp] * 10
+        L.c8o_set_calibration.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, dp, C.c_double, C.c_int, C.c_double,
+                                          C.c_double, C.c_int, C.c_double]
+        L.c8o_set_avg_disp.argtypes = [C.c_void_p]
+        L.c8o_set_measured.argtypes = [C.c_void_p, dp, C.c_double]
+        L.c8o_qoi_preprocess.restype = C.c_double
+        L.c8o_qoi_preprocess.argtypes = [C.c_void_p] + [dp] * 7
         L.c8o_kit_npts.restype = C.c_int
         L.c8o_kit_npts.argtypes = [C.c_int, C.c_int]
         L.c8o_kit_point.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
@@ -171,6 +177,25 @@ class Oracle:
 
     def eval_qoi(self, u, p):
         return self.L.c8o_eval_qoi(self.h, _d(u), _d(p))
+
+    # ---- Calibration QoI (calibration.cpp) ----
+    def set_calibration(self, faces, weights=(1.0, 1.0, 1.0), balance=1.0, coord_idx=1, coord_value=0.0,
+                        coord_tol=1e-8, comp=1, dt_over_T=1.0):
+        """faces: [nfaces][3 or 4] global node ids of the displacement side set; load plane: x[coord_idx] = value."""
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self.L.c8o_set_calibration(self.h, f.shape[0], f.shape[1], f.ctypes.data_as(ip), _d(w), balance, coord_idx,
+                                   coord_value, coord_tol, comp, dt_over_T)
+        self.calibration = True
+
+    def set_measured(self, u_meas, load_meas):
+        self.L.c8o_set_measured(self.h, _d(np.ascontiguousarray(u_meas, dtype=np.float64)), float(load_meas))
+
+    def qoi_preprocess(self, u, p, u_prev, p_prev, xi_prev, xi):
+        """preprocess_qoi: returns (area, total load, load mismatch) of the step."""
+        out = np.zeros(3)
+        self.L.c8o_qoi_preprocess(self.h, _d(u), _d(p), _d(u_prev), _d(p_prev), _d(xi_prev), _d(xi), _d(out))
+        return out
 
     def qoi_gradient(self, u, p, u_prev, p_prev, xi_prev, xi, z_u, z_p, phi, nparams):
         grad = np.zeros(nparams)

@@ -156,3 +156,66 @@ def test_adjoint_gradient_fd_check_small_J2():
     drop = np.log10(errs.max() / errs.min())
     assert drop > 7.0, (drop, errs, gd)
     assert errs.min() < 1e-7 * abs(gd), (errs.min(), gd)
+
+
+def calibration_bar(params, measured=None, nsteps=3, kind="hex8"):
+    """A bar pulled in y: displacement mismatch on the xmax face, reaction load on the ymin plane (component y)."""
+    c, conn, sets = brick(2, 3, 2, 1.0, 1.5, 1.0)
+    c = jiggle(c, sets, 0.0)
+    be = ol.Oracle(ol.HEX8, c, conn, "small_J2", params)
+    dbcs = [Dbc(0, 0, sets["xmin"], lambda x, y, z, t: 0.0), Dbc(0, 1, sets["ymin"], lambda x, y, z, t: 0.0),
+            Dbc(0, 2, sets["zmin"], lambda x, y, z, t: 0.0), Dbc(0, 1, sets["ymax"], lambda x, y, z, t: 0.002 * t)]
+    xmax = set(sets["xmax"].tolist())
+    faces = []
+    for e in conn:
+        for f in ([0, 1, 2, 3], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7], [4, 5, 6, 7]):
+            if all(int(e[k]) in xmax for k in f):
+                faces.append([int(e[k]) for k in f])
+    be.set_calibration(faces, weights=(1.0, 2.0, 0.5), balance=1e-4, coord_idx=1, coord_value=0.0, coord_tol=1e-8,
+                       comp=1, dt_over_T=1.0 / nsteps)
+    pr = Primal(be, c, dbcs, max_iters=15, abs_tol=1e-12, rel_tol=1e-12).solve(nsteps)
+    if measured is not None:
+        pr.measured = measured
+    return pr
+
+
+def test_calibration_qoi_value_and_fd_gradient():
+    # synthetic calibration (the reference's example set-up in small): "measurements" from the true parameters,
+    # objective = surface displacement mismatch + balance * load mismatch (calibration.cpp)
+    truth = np.array(J2)
+    pt = calibration_bar(truth)
+    nsteps = len(pt.u) - 1
+    loads = [0.0]
+    for s in range(1, nsteps + 1):
+        pt.be.set_measured(np.zeros_like(pt.u[s]), 0.0)
+        area, total, mism = pt.be.qoi_preprocess(pt.u[s], pt.p[s], pt.u[s - 1], pt.p[s - 1], pt.xi[s - 1], pt.xi[s])
+        loads.append(total)
+    assert abs(area - 1.5) < 1e-12            # the xmax face of the 1 x 1.5 x 1 bar
+    assert loads[-1] < 0 < abs(loads[1])      # pulling in +y: the reaction on the ymin plane points to -y
+    measured = ([None] + [u.copy() for u in pt.u[1:]], loads)
+    pt.measured = measured
+    assert abs(pt.qoi()) < 1e-20              # zero at the truth
+    base = truth * np.array([1.1, 1.0, 0.8, 0.9, 1.0, 1.0])
+
+    def objective(params):
+        return calibration_bar(params, measured).qoi()
+
+    pr = calibration_bar(base, measured)
+    J0 = pr.qoi()
+    assert J0 > 1e-12
+    assert pr.xi[-1][:, :, 6].max() > 1e-4    # plastic
+    active = [0, 1, 2, 3]
+    pr.be.set_active(0, active)
+    grad = adjoint_gradient(pr, len(active))
+    direction = np.array([100.0, 0.02, 10.0, 0.2])
+    gd = float(grad @ direction)
+    errs = []
+    for k in range(1, 9):
+        h = 10.0 ** (-k)
+        pp, pm = base.copy(), base.copy()
+        pp[active] += h * direction
+        pm[active] -= h * direction
+        errs.append(abs((objective(pp) - objective(pm)) / (2 * h) - gd))
+    errs = np.array(errs)
+    assert errs.min() < 1e-6 * abs(gd), (errs, gd)
+    assert np.log10(errs.max() / errs.min()) > 4.0, (errs, gd)
