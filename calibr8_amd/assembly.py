@@ -244,12 +244,41 @@ class Assembler:
         sy = ls.c_struct()
         return self._rc(self.L.c8_apply_A(self.h, C.byref(sy), x, y))
 
-    def eval_qoi(self, u, p, J, xi_prev=None, xi=None):
+    # ---- objective ----
+    def set_qoi_avg_disp(self):
+        _l.check(self.L.c8_set_qoi_avg_disp(self.h))
+
+    def set_qoi_calibration(self, faces, weights=(1.0, 1.0, 1.0), balance=1.0, coord_idx=1, coord_value=0.0,
+                            coord_tol=1e-8, comp=1, dt_over_T=1.0):
+        """Calibration objective (calibration.cpp): faces = node ids of the displacement side set [n][3|4] (host),
+        load plane = nodes with |x[coord_idx] - coord_value| < coord_tol, reaction component comp."""
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        d = _l.CalibrationDesc()
+        d.num_faces, d.nodes_per_face, d.faces = f.shape[0], f.shape[1], f.ctypes.data
+        for k in range(3):
+            d.weights[k] = float(weights[k])
+        d.balance_factor, d.coord_idx, d.coord_value, d.coord_tol = float(balance), int(coord_idx), float(coord_value), float(coord_tol)
+        d.reaction_comp, d.dt_over_total_time = int(comp), float(dt_over_T)
+        _l.check(self.L.c8_set_qoi_calibration(self.h, C.byref(d)))
+
+    def set_measured(self, u_meas, load_meas):
+        """measured nodal displacements of the step (device tensor, kept by reference) and measured load"""
+        self._u_meas = u_meas
+        _l.check(self.L.c8_set_measured(self.h, C.c_void_p(u_meas.data_ptr()), float(load_meas)))
+
+    def qoi_preprocess(self, u, p, u_prev, p_prev, xi_prev, xi):
+        """preprocess_qoi: (side-set area, total load, load mismatch)"""
+        st = self._state(u, p, u_prev, p_prev, xi_prev, xi)
+        out = (C.c_double * 3)()
+        _l.check(self.L.c8_qoi_preprocess(self.h, C.byref(st), out))
+        return tuple(out)
+
+    def eval_qoi(self, u, p, J, xi_prev=None, xi=None, u_prev=None, p_prev=None):
         """eval_qoi: J (1-element device tensor) += QoI value.  The local state is only needed by QoIs
         that read it ("average displacement" does not)."""
         s = _l.State()
         s.x[0], s.x[1] = u.data_ptr(), p.data_ptr()
-        s.x_prev[0], s.x_prev[1] = u.data_ptr(), p.data_ptr()
+        s.x_prev[0], s.x_prev[1] = (u_prev if u_prev is not None else u).data_ptr(), (p_prev if p_prev is not None else p).data_ptr()
         s.xi_prev = xi_prev.data_ptr() if xi_prev is not None else None
         s.xi = xi.data_ptr() if xi is not None else None
         return self._rc(self.L.c8_eval_qoi(self.h, C.byref(s), C.c_void_p(J.data_ptr())))

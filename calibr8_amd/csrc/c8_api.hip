@@ -133,7 +133,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
   stage_release(c);
-  void* bufs[] = {c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
+  void* bufs[] = {c->d_cal_faces, c->d_cal_S, c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
@@ -367,15 +367,23 @@ int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const
       if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null A block");
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
-  AdjointArgs aa{g, const_cast<double*>(f), nullptr, nullptr, nullptr, nullptr, c->d_active};
+  int rc = c8_qoi_prepare(c, field_args(st));  // preprocess_qoi (evaluations.cpp:365)
+  if (rc) return rc;
+  AdjointArgs aa{g, const_cast<double*>(f), nullptr, nullptr, nullptr, nullptr, c->d_active, c8_qoi_args(c)};
   LaunchFn fn = c->ks.adjoint_jacobian;
   if (c->ks.adjoint_jacobian_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.adjoint_jacobian_wave;
-  return run(c, fn, field_args(st), aa, sa, true, "c8_assemble_adjoint_jacobian");
+  int const async = c->async;
+  c->async = 1;  // the face term of the objective is enqueued before the status is read back
+  rc = run(c, fn, field_args(st), aa, sa, true, "c8_assemble_adjoint_jacobian");
+  c->async = async;
+  if (rc) return rc;
+  if ((rc = c8_qoi_surface(c, st->x[0], nullptr, sys->b[0]))) return rc;
+  return async ? C8_OK : c8_status(c);
 }
 
 int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[2], double* phi, double* g, double* f) {
   if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !g || !f) return fail(C8_ERR_ARG, "c8_solve_adjoint_local: null argument");
-  AdjointArgs aa{g, f, z[0], z[1], phi, nullptr, c->d_active};
+  AdjointArgs aa{g, f, z[0], z[1], phi, nullptr, c->d_active, c8_qoi_args(c)};
   LaunchFn fn = c->ks.adjoint_local;
   if (c->ks.adjoint_local_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.adjoint_local_wave;
   return run(c, fn, field_args(st), aa, SystemArgs{}, false, "c8_solve_adjoint_local");
@@ -383,7 +391,9 @@ int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[
 
 int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], const double* phi, double* grad) {
   if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !grad) return fail(C8_ERR_ARG, "c8_param_gradient: null argument");
-  AdjointArgs aa{nullptr, nullptr, z[0], z[1], const_cast<double*>(phi), grad, c->d_active};
+  int const rcq = c8_qoi_prepare(c, field_args(st));  // preprocess_qoi (evaluations.cpp:780)
+  if (rcq) return rcq;
+  AdjointArgs aa{nullptr, nullptr, z[0], z[1], const_cast<double*>(phi), grad, c->d_active, c8_qoi_args(c)};
   LaunchFn fn = c->ks.param_gradient;
   if (c->ks.param_gradient_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.param_gradient_wave;
   return run(c, fn, field_args(st), aa, SystemArgs{}, false, "c8_param_gradient");
@@ -392,8 +402,16 @@ int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], c
 int c8_eval_qoi(c8_ctx* c, const c8_state* st, double* J) {
   if (!c || !st || !st->x[0] || !st->x[1] || !J) return fail(C8_ERR_ARG, "c8_eval_qoi: null argument");
   FieldArgs fa{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
-  AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, J, c->d_active};
-  return run(c, c->ks.qoi, fa, aa, SystemArgs{}, false, "c8_eval_qoi");
+  if (c->qoi_kind == 0) {
+    AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, J, c->d_active, c8_qoi_args(c)};
+    return run(c, c->ks.qoi, fa, aa, SystemArgs{}, false, "c8_eval_qoi");
+  }
+  // calibration (Calibration<double>::evaluate + postprocess): preprocess_qoi (evaluations.cpp:674), the face
+  // term, and 1/2 balance dt/T load_mismatch^2
+  if (!st->xi || !st->xi_prev) return fail(C8_ERR_ARG, "c8_eval_qoi: the calibration objective needs the local state");
+  int rc = c8_qoi_prepare(c, fa);
+  if (rc || (rc = c8_qoi_surface(c, st->x[0], J, nullptr)) || (rc = c8_qoi_postprocess(c, J))) return rc;
+  return c->async ? C8_OK : c8_status(c);
 }
 
 int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, double* coords, int32_t* conn) {

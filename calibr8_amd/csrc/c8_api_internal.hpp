@@ -44,6 +44,14 @@ struct c8_ctx {
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
   int* d_status = nullptr;
   unsigned long long* d_stamps = nullptr;  // -DC8_STAMPS diagnostic build only
+  // objective: 0 = average displacement, 1 = calibration (c8_qoi.hip)
+  int qoi_kind = 0;
+  int32_t* d_cal_faces = nullptr;   // [cal_nfaces][4] node ids of the element faces on the displacement side set
+  double* d_cal_S = nullptr;        // [nelems][coupled points][3] load-plane sums of grad N
+  double const* d_u_meas = nullptr; // caller's measured displacement of the current step (device)
+  int cal_nfaces = 0, cal_nf = 0, cal_comp = 0;
+  double cal_area = 0., cal_w[3] = {1., 1., 1.}, cal_balance = 0., cal_dt_over_T = 1.;
+  double cal_load_meas = 0., cal_total_load = 0., cal_load_mismatch = 0.;
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
   int kernel_variant = C8_KERNEL_AUTO;
@@ -52,3 +60,9 @@ struct c8_ctx {
   int subset_count = 0;
 };
 
+
+// c8_qoi.hip
+c8::QoiArgs c8_qoi_args(c8_ctx const* c);
+int c8_qoi_prepare(c8_ctx* c, c8::FieldArgs const& fa);
+int c8_qoi_surface(c8_ctx* c, double const* u, double* J, double* b0);
+int c8_qoi_postprocess(c8_ctx* c, double* J);

@@ -64,6 +64,7 @@ struct AdjointArgs {
   double* phi;         // local adjoint [nelems][NP0][NLOC]
   double* out;         // grad [n_active] (K5) or J [1] (K6)
   int32_t const* active;  // [nsets][2 + 8]: {offset into grad, n_active, param indices...}
+  QoiArgs qoi;            // objective integrand (default: average displacement)
 };
 struct SystemArgs {
   double* A[2][2];  // CSR values of the four blocks

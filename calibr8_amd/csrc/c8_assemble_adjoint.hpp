@@ -198,11 +198,11 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           accumulate_coupled<E>(sh, pt, k, f, r.Jcol, dummy);
           C8_UNROLL
           for (int j = 0; j < NL; ++j) r.m.xi[j].d = 0.;
-          double const dJ_dx = QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;
+          double const dJ_dx = QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, qp).d;
           unseed(r.g);
           C8_UNROLL
           for (int j = 0; j < NL; ++j) r.m.xi[j].d = (j == k) ? 1. : 0.;
-          double const dJ_dxi = QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;
+          double const dJ_dxi = QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, qp).d;
           C8_UNROLL
           for (int j = 0; j < NL; ++j) r.m.xi[j].d = 0.;
           if (k < NL) {
@@ -407,7 +407,7 @@ C8_HD void param_gradient_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh
           double s = 0.;
           C8_UNROLL
           for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];  // (dC/dp)^T phi (:864-866)
-          s += QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;                        // dJ/dp (:869-871)
+          s += QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, qp).d;               // dJ/dp (:869-871)
           MechFlux<Dual> f;
           Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
           s += flux_dot_adjoint<E>(sh, pt, f, true);                         // (dR/dp)^T z (:883-886)
@@ -443,7 +443,8 @@ template <class E, template <class> class ModelT> struct QoiLane {
 };
 
 template <class E, template <class> class ModelT, class QoI, class EX>
-C8_HD void qoi_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, FieldArgs const& fa, int e) {
+C8_HD void qoi_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, FieldArgs const& fa,
+                       QoiArgs const& qa, int e) {
   using Model = ModelT<double>;
   constexpr int NL = Model::NLOC;
   load_element<E>(ex, sh, mt, fa, e, false);
@@ -461,7 +462,7 @@ C8_HD void qoi_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, MeshTable
       r.m.xi[j] = fa.xi ? fa.xi[qp * NL + j] : 0.;
       r.m.xi_prev[j] = fa.xi_prev ? fa.xi_prev[qp * NL + j] : 0.;
     }
-    r.acc += QoI::evaluate(r.g, r.m, sh.wdv[k]);
+    r.acc += QoI::evaluate(r.g, r.m, sh.wdv[k], qa, qp);
   });
   ex.sync();
 }

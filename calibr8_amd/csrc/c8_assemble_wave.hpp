@@ -260,7 +260,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
           for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.m.R[j].d;
         }
       }
-      double const dJ_dxi = QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;
+      double const dJ_dxi = QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, (size_t)e * E::NP0 + pt).d;
       if (d < NL) {
         size_t const qg = ((size_t)e * E::NP0 + pt) * NL + d;
         double const gk = aa.g[qg] - dJ_dxi;
@@ -377,7 +377,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
         for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].d;
       }
       double dJ_dq = 0.;
-      if (ADJOINT) dJ_dq = QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;  // x seeded, xi plain (:469-471)
+      if (ADJOINT) dJ_dq = QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, (size_t)e * E::NP0 + pt).d;  // x seeded, xi plain (:469-471)
       // dxi/dq_c = -(dC/dxi)^-1 dC/dq_c  (evaluations.cpp:112; local->seed_wrt_x, chain rule through q)
       if (Model::HAS_LOCAL && need_inverse) {
         C8_UNROLL
@@ -657,7 +657,7 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
 template <class E, template <class> class ModelT, class EX>
 C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
                                  ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
-  jacobian_wave<E, ModelT, AvgDisp, false>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
+  jacobian_wave<E, ModelT, PointQoi, false>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
 }
 
 template <class E, template <class> class ModelT, class QoI, class EX>
@@ -916,7 +916,7 @@ C8_HD void param_gradient_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, M
     double s = 0.;
     C8_UNROLL
     for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];   // (dC/dp)^T phi
-    s += QoI::evaluate(r.g, r.m, sh.wdv[pt]).d;                          // dJ/dp
+    s += QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, qp).d;                 // dJ/dp
     MechFlux<Dual> f;
     Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
     f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);                    // both ip sets (same points)

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_adjoint_jacobian_wave(MeshTables m
   int const e = mt.order ? mt.order[first + gi] : first + gi;
   Lane L;
   GpuExec<Lane> ex(lane, L);
-  adjoint_jacobian_wave<E, ModelT, AvgDisp>(ex, shs[wib], mt, ms, fa, aa, sa, e);
+  adjoint_jacobian_wave<E, ModelT, PointQoi>(ex, shs[wib], mt, ms, fa, aa, sa, e);
 }
 
 template <class E, template <class> class ModelT>
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_param_gradient_wave(MeshTables mt,
   L.acc = 0.;
   GpuExec<Lane> ex(lane, L);
   for (int e = blockIdx.x * WPB + wib; e < count; e += gridDim.x * WPB)
-    param_gradient_wave<E, ModelT, AvgDisp>(ex, shs[wib], mt, ms, fa, aa, e);
+    param_gradient_wave<E, ModelT, PointQoi>(ex, shs[wib], mt, ms, fa, aa, e);
   param_gradient_wave_flush(ex, aa);
 }
 
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(BLOCK) k_adjoint_jacobian(MeshTables mt, Model
   __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
   Lane L;
   GpuExec<Lane> ex(k, L);
-  adjoint_jacobian_element<E, ModelT, AvgDisp>(ex, shs[gib], mt, ms, fa, aa, sa, e);
+  adjoint_jacobian_element<E, ModelT, PointQoi>(ex, shs[gib], mt, ms, fa, aa, sa, e);
 }
 
 template <class E, template <class> class ModelT>
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(BLOCK) k_param_gradient(MeshTables mt, ModelSe
   L.acc = 0.;
   GpuExec<Lane> ex(k, L);
   for (int e = blockIdx.x * GPB + gib; e < count; e += gridDim.x * GPB)
-    param_gradient_element<E, ModelT, AvgDisp>(ex, shs[gib], mt, ms, fa, aa, e);
+    param_gradient_element<E, ModelT, PointQoi>(ex, shs[gib], mt, ms, fa, aa, e);
   param_gradient_flush(ex, aa);
 }
 
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(BLOCK) k_qoi(MeshTables mt, FieldArgs fa, Adjo
   L.acc = 0.;
   GpuExec<Lane> ex(k, L);
   for (int e = blockIdx.x * GPB + gib; e < count; e += gridDim.x * GPB)
-    qoi_element<E, ModelT, AvgDisp>(ex, shs[gib], mt, fa, e);
+    qoi_element<E, ModelT, PointQoi>(ex, shs[gib], mt, fa, aa.qoi, e);
   qoi_flush<E>(ex, aa.out);
 }
 

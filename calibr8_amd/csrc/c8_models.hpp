@@ -251,21 +251,46 @@ struct Mechanics {
     }
     f.Gu = stress;
   }
+  // the displacement flux alone (sigma, or PK1 = sigma cof F): R_u[n][i] = sum_j Gu[i][j] dN_n/dx_j w dv (:136-144)
+  template <class T, class Local> C8_HD static Tens3<T> flux_u(Local const& local, PointState<T> const& g) {
+    Tens3<T> stress = local.cauchy(g);
+    if (Local::FINITE_DEF) stress = matmul(stress, cofactor(g.grad_u + eye3<T>()));
+    return stress;
+  }
   template <class T, class Local>
   C8_HD static T flux_pressure(Local const& local, PointState<T> const& g) {  // :215-223
     return -(g.p / local.pressure_scale_factor());
   }
 };
 
-// ---- QoI concept (qoi.hpp): value_pt of the objective integrand at a point ---------------
-// "average displacement", avg_disp.cpp:16-33: J_pt = sum_i u_i w dv / ndims
-struct AvgDisp {
+// ---- QoI concept (qoi.hpp): value_pt of the objective integrand at a coupled point ---------------
+// One integrand with run-time coefficients covers the reference's two point-wise objectives, so that the
+// adjoint kernels are compiled once:
+//   "average displacement" (avg_disp.cpp:16-33):       c_avg  * sum_i u_i w dv / ndims
+//   the load term of "calibration" (calibration.cpp:302-343, :468-472): the internal force of the coupled weak
+//   form summed over the element's nodes on the load plane, sum_n R_u[n][comp] = w dv Gu[comp][.] . S with
+//   S = sum_n grad N_n, times c_load = balance * dt/T * load_mismatch.
+// (The displacement-mismatch term of "calibration" lives on faces and is linear-quadratic in the nodal values:
+// c8_primal.hip adds it and its derivative directly.)
+struct QoiArgs {
+  double c_avg, c_load;
+  int comp;
+  double const* S;  // [nelems][coupled points][3], null when c_load == 0
+};
+struct PointQoi {
   template <class T, class Local>
-  C8_HD static T evaluate(PointState<T> const& g, Local const&, double wdv) {
-    T v = g.u[0] * wdv;
-    v = v + g.u[1] * wdv;
-    v = v + g.u[2] * wdv;
-    return v / 3.;
+  C8_HD static T evaluate(PointState<T> const& g, Local const& local, double wdv, QoiArgs const& qa, size_t qp) {
+    T v = (g.u[0] + g.u[1] + g.u[2]) * (qa.c_avg * wdv / 3.);
+    if (qa.c_load != 0.) {  // uniform over the launch
+      Tens3<T> const Gu = Mechanics::flux_u(local, g);
+      double const s0 = qa.S[qp * 3] * (qa.c_load * wdv), s1 = qa.S[qp * 3 + 1] * (qa.c_load * wdv),
+                   s2 = qa.S[qp * 3 + 2] * (qa.c_load * wdv);
+      T const r0 = Gu.xx * s0 + Gu.xy * s1 + Gu.xz * s2;
+      T const r1 = Gu.yx * s0 + Gu.yy * s1 + Gu.yz * s2;
+      T const r2 = Gu.zx * s0 + Gu.zy * s1 + Gu.zz * s2;
+      v = v + (qa.comp == 0 ? r0 : (qa.comp == 1 ? r1 : r2));
+    }
+    return v;
   }
 };
 

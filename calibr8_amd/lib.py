@@ -49,6 +49,13 @@ class NewtonOpts(C.Structure):
                 ("max_evals", C.c_int32)]
 
 
+class CalibrationDesc(C.Structure):
+    _fields_ = [("num_faces", C.c_int32), ("nodes_per_face", C.c_int32), ("faces", C.c_void_p),
+                ("weights", C.c_double * 3), ("balance_factor", C.c_double), ("coord_idx", C.c_int32),
+                ("coord_value", C.c_double), ("coord_tol", C.c_double), ("reaction_comp", C.c_int32),
+                ("dt_over_total_time", C.c_double)]
+
+
 class State(C.Structure):
     _fields_ = [("x", C.c_void_p * 2), ("x_prev", C.c_void_p * 2), ("xi_prev", C.c_void_p), ("xi", C.c_void_p)]
 
@@ -79,6 +86,10 @@ SYMBOLS = [
     ("c8_set_kernel_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_status", C.c_int, [C.c_void_p]),
+    ("c8_set_qoi_avg_disp", C.c_int, [C.c_void_p]),
+    ("c8_set_qoi_calibration", C.c_int, [C.c_void_p, C.POINTER(CalibrationDesc)]),
+    ("c8_set_measured", C.c_int, [C.c_void_p, C.c_void_p, C.c_double]),
+    ("c8_qoi_preprocess", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(C.c_double)]),
     ("c8_assemble_forward_jacobian", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),
     ("c8_assemble_forward_jacobian_subset", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System), C.c_void_p, C.c_int]),
     ("c8_assemble_residual", C.c_int, [C.c_void_p, C.POINTER(State), C.POINTER(System)]),

@@ -137,10 +137,20 @@ class PrimalDriver:
             self.solve_at_step(s)
         return self
 
+    def set_measured(self, u_meas, loads):
+        """Calibration objective: measured displacements (device tensors) and loads per step, index 0 unused."""
+        self.measured = (u_meas, loads)
+
+    def begin_qoi_step(self, s):
+        if getattr(self, "measured", None) is not None:
+            self.asm.set_measured(self.measured[0][s], self.measured[1][s])
+
     def qoi(self):
         J = self.torch.zeros(1, dtype=self.torch.float64, device=self.asm.device)
         for s in range(1, len(self.u)):
-            self.asm.eval_qoi(self.u[s], self.p[s], J)
+            self.begin_qoi_step(s)
+            self.asm.eval_qoi(self.u[s], self.p[s], J, xi_prev=self.xi[s - 1], xi=self.xi[s], u_prev=self.u[s - 1],
+                              p_prev=self.p[s - 1])
         self.torch.cuda.synchronize()
         return float(J.item())
 
@@ -164,6 +174,7 @@ def adjoint_gradient(primal, nparams):
     for k, (resid, eq, nodes, _) in enumerate(primal.dbcs):
         d[k] = _l.Dbc(resid, eq, len(nodes), primal._dbc_nodes[k].data_ptr(), zero_vals[k].data_ptr())
     for step in range(nsteps, 0, -1):
+        primal.begin_qoi_step(step)
         st = asm._state(primal.u[step], primal.p[step], primal.u[step - 1], primal.p[step - 1], primal.xi[step - 1],
                         primal.xi[step])
         z = (C.c_void_p * 2)(z_u.data_ptr(), z_p.data_ptr())

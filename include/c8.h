@@ -127,6 +127,31 @@ int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 int c8_set_async(c8_ctx* ctx, int async);
 int c8_status(c8_ctx* ctx);
 
+/* ---- the objective (QoI) of the adjoint path ---------------------------------------------------------
+ * Default: "average displacement" (avg_disp.cpp).  "calibration" (calibration.cpp, 3-D form):
+ *   J_step = dt/T [ 1/(2 area) int_side sum_d w_d (u_d - u_meas_d)^2 dS * (coupled points per element)
+ *                   + 1/2 balance (load - load_meas)^2 ],
+ * load = internal force component `reaction_comp` summed over the nodes with |x[coord_idx] - coord_value| <
+ * coord_tol.  The factor "coupled points per element" is the reference's: it adds the face integral at every
+ * coupled integration point of the element (1 for tet4, 8 for this library's hex8 extension). */
+typedef struct {
+  int32_t num_faces, nodes_per_face;  /* displacement side set: faces as node ids, 3 per face (tet4) or 4 (hex8) */
+  const int32_t* faces;               /* HOST array [num_faces][nodes_per_face] */
+  double weights[3];                  /* "displacement weights" */
+  double balance_factor;
+  int32_t coord_idx;                  /* "coordinate index" / "coordinate value" / "coordinate tolerance" */
+  double coord_value, coord_tol;
+  int32_t reaction_comp;              /* "reaction force component" */
+  double dt_over_total_time;          /* m_dt / m_total_time */
+} c8_calibration_desc;
+int c8_set_qoi_avg_disp(c8_ctx* ctx);
+int c8_set_qoi_calibration(c8_ctx* ctx, const c8_calibration_desc* desc);
+/* measured data of the current step: nodal displacements (DEVICE array [nodes][3], kept by reference) and load */
+int c8_set_measured(c8_ctx* ctx, const double* u_meas, double load_meas);
+/* preprocess_qoi (evaluations.cpp:262-347); the adjoint entry points below run it themselves, this call only
+ * reports: out (HOST, 3 doubles, may be NULL) = {side-set area, total load, load mismatch}. */
+int c8_qoi_preprocess(c8_ctx* ctx, const c8_state* st, double* out);
+
 /* ---- the hot path (all array arguments are DEVICE pointers) --------------------------------- */
 /* eval_forward_jacobian (evaluations.cpp:12-154): R and dR/dx with the local state condensed;
  * writes the converged local state to st->xi. */
@@ -137,7 +162,7 @@ int c8_assemble_forward_jacobian(c8_ctx* ctx, const c8_state* st, const c8_syste
 int c8_assemble_forward_jacobian_subset(c8_ctx* ctx, const c8_state* st, const c8_system* sys, const int32_t* elems, int count);
 /* eval_global_residual (evaluations.cpp:156-259): R only, from the stored local state. */
 int c8_assemble_residual(c8_ctx* ctx, const c8_state* st, const c8_system* sys);
-/* eval_adjoint_jacobian (evaluations.cpp:349-526), QoI = "average displacement":
+/* eval_adjoint_jacobian (evaluations.cpp:349-526) for the context's objective:
  * A += (dR/dx total)^T, b += -dJ/dx + f + (dxi/dx)^T g, and g -= dJ/dxi in place.
  * g [elems][points][local dofs], f [elems][points][element dofs]. */
 int c8_assemble_adjoint_jacobian(c8_ctx* ctx, const c8_state* st, double* g, const double* f, const c8_system* sys);

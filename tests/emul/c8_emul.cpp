@@ -61,7 +61,7 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
     delete ex;
   } else if (c.what == K_ADJ_JAC) {
     auto* ex = new CpuExec<AdjointLane<E, ModelT>, E::NDOF>();
-    for (int e = 0; e < c.nelems; ++e) adjoint_jacobian_element<E, ModelT, AvgDisp>(*ex, sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+    for (int e = 0; e < c.nelems; ++e) adjoint_jacobian_element<E, ModelT, PointQoi>(*ex, sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
     delete ex;
   } else if (c.what == K_ADJ_LOCAL) {
     auto* ex = new CpuExec<AdjointLane<E, ModelT>, E::NDOF>();
@@ -70,13 +70,13 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
   } else if (c.what == K_GRAD) {
     auto* ex = new CpuExec<GradLane<E, ModelT>, E::NDOF>();
     for (int k = 0; k < E::NDOF; ++k) { ex->lanes[k].slot = -1; ex->lanes[k].acc = 0.; }
-    for (int e = 0; e < c.nelems; ++e) param_gradient_element<E, ModelT, AvgDisp>(*ex, sh, c.mt, c.ms, c.fa, c.aa, e);
+    for (int e = 0; e < c.nelems; ++e) param_gradient_element<E, ModelT, PointQoi>(*ex, sh, c.mt, c.ms, c.fa, c.aa, e);
     param_gradient_flush(*ex, c.aa);
     delete ex;
   } else if (c.what == K_QOI) {
     auto* ex = new CpuExec<QoiLane<E, ModelT>, E::NDOF>();
     for (int k = 0; k < E::NDOF; ++k) ex->lanes[k].acc = 0.;
-    for (int e = 0; e < c.nelems; ++e) qoi_element<E, ModelT, AvgDisp>(*ex, sh, c.mt, c.fa, e);
+    for (int e = 0; e < c.nelems; ++e) qoi_element<E, ModelT, PointQoi>(*ex, sh, c.mt, c.fa, c.aa.qoi, e);
     qoi_flush<E>(*ex, c.aa.out);
     delete ex;
   }
@@ -89,7 +89,7 @@ template <template <class> class ModelT> static void run_wave_adjoint(Call const
   for (int k = 0; k < 64; ++k) { ex->lanes[k].slot = -1; ex->lanes[k].acc = 0.; }
   for (int e = 0; e < c.nelems; ++e) {
     if (c.what == K_ADJ_LOCAL_WAVE) adjoint_local_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
-    else param_gradient_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e);
+    else param_gradient_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e);
   }
   if (c.what == K_GRAD_WAVE) param_gradient_wave_flush(*ex, c.aa);
   delete ex;
@@ -104,7 +104,7 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   if (!c.staged) {
     for (int e = 0; e < c.nelems; ++e) {
       if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
-      else adjoint_jacobian_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
+      else adjoint_jacobian_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
     }
   } else {
     // staged assembly in the order the stream pipeline of c8_api.hip produces: chunk k into the ring, then the
@@ -122,7 +122,7 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
       int const e1 = std::min(c.nelems, (k + 1) * pl.chunk);
       for (int e = k * pl.chunk; e < e1; ++e) {
         if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
-        else adjoint_jacobian_wave<E, ModelT, AvgDisp>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
+        else adjoint_jacobian_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
       }
       for (int q = pl.node_off[k]; q < pl.node_off[k + 1]; ++q) gather_node_rows<E, GATHER_MAX_DEGREE>(*gex, *gsh, ga, pl.node_order[q]);
     }
@@ -187,7 +187,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
   c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
   c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};
-  c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active};
+  c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active, QoiArgs{1., 0., 0, nullptr}};
   int const rc = (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c);
   if (rc != 0) return rc;
   return status ? -1 : 0;

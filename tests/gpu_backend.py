@@ -100,5 +100,22 @@ class GpuBackend:
     def eval_qoi(self, u, p):
         a = self.asm
         J = a.dev(np.zeros(1))
-        a.eval_qoi(a.dev(u), a.dev(p), J)
+        st = getattr(self, "_qoi_state", None)
+        if st is None:
+            a.eval_qoi(a.dev(u), a.dev(p), J)
+        else:  # calibration: the state of the step given to qoi_preprocess
+            a.eval_qoi(a.dev(u), a.dev(p), J, xi_prev=st[4], xi=st[5], u_prev=st[2], p_prev=st[3])
         return float(J.cpu().numpy()[0])
+
+    # ---- Calibration objective ----
+    def set_calibration(self, faces, **kw):
+        self.asm.set_qoi_calibration(faces, **kw)
+        self.calibration = True
+
+    def set_measured(self, u_meas, load_meas):
+        self.asm.set_measured(self.asm.dev(np.ascontiguousarray(u_meas, dtype=np.float64)), load_meas)
+
+    def qoi_preprocess(self, u, p, u_prev, p_prev, xi_prev, xi):
+        a = self.asm
+        self._qoi_state = [a.dev(v) for v in (u, p, u_prev, p_prev, xi_prev, xi)]
+        return np.array(a.qoi_preprocess(*self._qoi_state))

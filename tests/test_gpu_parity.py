@@ -248,3 +248,63 @@ def test_large_brick_properties():
     shift = np.tile([0.3, -0.2, 0.1], len(p))
     gc.forward_jacobian(u + shift, p, z, zp, gc.new_state(), gc.new_state(), lt)
     assert rel_vec(lt.b[0], lc.b[0]) < 1e-12 and rel_vec(lt.A[0][0], lc.A[0][0]) < 1e-12
+
+
+def _calibration_pair(kind):
+    """oracle and GPU backend with the Calibration objective on the same mesh: displacement side set = the xmax
+    boundary faces, load plane y = 0, component y"""
+    from gpu_backend import GpuBackend
+    from parity_cases import mesh_of
+    et, c, conn = mesh_of(kind) if kind == "tet4" else (ol.HEX8,) + tuple(hex_mesh((3, 4, 2)))
+    xmax, ymin = c[:, 0].max(), c[:, 1].min()
+    loc_faces = ([0, 1, 2], [0, 1, 3], [1, 2, 3], [0, 2, 3]) if et == ol.TET4 else \
+        ([0, 1, 2, 3], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7], [4, 5, 6, 7])
+    faces = [[int(e[k]) for k in f] for e in conn for f in loc_faces if all(abs(c[e[k], 0] - xmax) < 1e-9 for k in f)]
+    assert faces
+    kw = dict(weights=(1.0, 2.0, 0.5), balance=0.3, coord_idx=1, coord_value=float(ymin), coord_tol=1e-6, comp=1,
+              dt_over_T=0.5)
+    orc = ol.Oracle(et, c, conn, "small_J2", J2)
+    gpu = GpuBackend(et, c, conn, "small_J2", J2, scatter="atomic")
+    orc.set_calibration(faces, **kw)
+    gpu.set_calibration(faces, **kw)
+    return orc, gpu, c
+
+
+@pytest.mark.parametrize("kind", ["hex8", "tet4"])
+def test_calibration_objective_matches_oracle(kind):
+    # Calibration QoI (calibration.cpp): preprocess (total load), value, and its x / xi / parameter derivatives
+    # through K3 -> K4 -> K5, against the oracle
+    from parity_cases import two_steps
+    orc, gpu, c = _calibration_pair(kind)
+    if kind == "tet4":
+        pytest.importorskip("numpy")
+    st = two_steps(orc, c, 0.004)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    rng = np.random.default_rng(3)
+    u_meas = u + 1e-4 * rng.standard_normal(len(u))
+    for b in (orc, gpu):
+        b.set_active(0, [0, 1, 2, 3])
+        b.set_measured(u_meas, -0.7)
+    po = orc.qoi_preprocess(u, p, up, pp, xip, xi)
+    pg = gpu.qoi_preprocess(u, p, up, pp, xip, xi)
+    assert np.abs(po - pg).max() < 1e-12 * max(1.0, np.abs(po).max()), (po, pg)
+    assert abs(po[2]) > 1e-3  # a real load mismatch
+    Jo, Jg = orc.eval_qoi(u, p), gpu.eval_qoi(u, p)
+    assert abs(Jo - Jg) < 1e-12 * abs(Jo), (Jo, Jg)
+    nd = 4 * orc.nn
+    res = []
+    for b in (orc, gpu):
+        g = rng.standard_normal((orc.nelems, orc.npts, orc.nloc)) * 0 + 0.01
+        f = np.full((orc.nelems, orc.npts, nd), 0.02)
+        ls = b.new_linsys()
+        b.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, ls)
+        z_u, z_p = np.linspace(-1e-3, 1e-3, len(u)), np.linspace(2e-3, -1e-3, len(p))
+        phi = np.zeros_like(g)
+        b.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
+        grad = b.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 4)
+        res.append((ls, g, f, phi, grad))
+    (lo, go, fo, pho, gro), (lg, gg, fg, phg, grg) = res
+    errs = compare_systems(orc, lg, lo)
+    errs["g"], errs["f"], errs["phi"] = rel_vec(gg, go), rel_vec(fg, fo), rel_vec(phg, pho)
+    errs["grad"] = float(np.abs(grg - gro).max() / np.abs(gro).max())
+    assert max(errs.values()) < TOL, errs

@@ -169,3 +169,58 @@ def test_device_adjoint_driver_gradient():
     # this bar problem is nearly linear in the parameters: central differences agree with the adjoint at every
     # step size (no visible error drop), so the check is the agreement itself
     assert min(errs) < 1e-7 * abs(gd) and max(errs) < 1e-4 * abs(gd), (errs, gd)
+
+
+def test_device_synthetic_calibration_objective_and_gradient():
+    # the reference's inverse-problem set-up in small, everything on the device: "measurements" (surface
+    # displacements on xmax, reaction load on ymin) from the true parameters; at perturbed parameters the
+    # Calibration objective (calibration.cpp) and its adjoint gradient, checked by central differences
+    import torch
+    from calibr8_amd import Assembler, PrimalDriver, adjoint_gradient
+    c, conn, sets = brick(3, 4, 2, 1.0, 1.5, 1.0)
+    zero = lambda x, y, z, t: 0.0
+    spec = [(0, 0, sets["xmin"], zero), (0, 1, sets["ymin"], zero), (0, 2, sets["zmin"], zero),
+            (0, 1, sets["ymax"], lambda x, y, z, t: 0.002 * t)]
+    xmax = set(sets["xmax"].tolist())
+    loc = ([0, 1, 2, 3], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7], [4, 5, 6, 7])
+    faces = [[int(e[k]) for k in f] for e in conn for f in loc if all(int(e[k]) in xmax for k in f)]
+    act, nsteps = [0, 1, 2, 3], 3
+    truth = np.array(J2)
+
+    def solve(params, measured=None):
+        asm = Assembler(8, c, conn, "small_J2", params)
+        asm.set_active(0, act)
+        asm.set_qoi_calibration(faces, weights=(1.0, 2.0, 0.5), balance=1e-4, coord_idx=1, coord_value=0.0,
+                                coord_tol=1e-8, comp=1, dt_over_T=1.0 / nsteps)
+        pr = PrimalDriver(asm, spec, max_iters=15, abs_tol=1e-12, rel_tol=1e-12).solve(nsteps)
+        if measured is not None:
+            pr.set_measured(*measured)
+        return pr
+
+    pt = solve(truth)
+    loads = [0.0]
+    zero_meas = torch.zeros_like(pt.u[1])
+    for s in range(1, nsteps + 1):
+        pt.asm.set_measured(zero_meas, 0.0)
+        area, total, _ = pt.asm.qoi_preprocess(pt.u[s], pt.p[s], pt.u[s - 1], pt.p[s - 1], pt.xi[s - 1], pt.xi[s])
+        loads.append(total)
+    assert abs(area - 1.5) < 1e-12 and loads[-1] < -1.0
+    measured = ([None] + [u.clone() for u in pt.u[1:]], loads)
+    pt.set_measured(*measured)
+    assert abs(pt.qoi()) < 1e-18
+    base = truth * np.array([1.1, 1.0, 0.8, 0.9, 1.0, 1.0])
+    pr = solve(base, measured)
+    J0 = pr.qoi()
+    assert J0 > 1e-12 and float(pr.xi[-1][:, :, 6].max()) > 1e-4
+    grad = adjoint_gradient(pr, len(act))
+    direction = np.array([100.0, 0.02, 10.0, 0.2])
+    gd = float(grad @ direction)
+    errs = []
+    for k in (2, 3, 4, 5):
+        h = 10.0 ** (-k)
+        pp, pm = base.copy(), base.copy()
+        pp[act] += h * direction
+        pm[act] -= h * direction
+        errs.append(abs((solve(pp, measured).qoi() - solve(pm, measured).qoi()) / (2 * h) - gd))
+    assert min(errs) < 1e-7 * abs(gd), (errs, gd)
+    assert errs[0] > 10 * min(errs), (errs, gd)  # second-order convergence of the difference quotient is visible
