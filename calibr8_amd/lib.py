@@ -56,6 +56,19 @@ class CalibrationDesc(C.Structure):
                 ("dt_over_total_time", C.c_double)]
 
 
+class LbfgsOpts(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("grad_tol", C.c_double), ("step_tol", C.c_double),
+                ("max_ls_evals", C.c_int32), ("memory", C.c_int32)]
+
+
+class LbfgsResult(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("evals", C.c_int32), ("status", C.c_int32), ("f", C.c_double),
+                ("projected_gradient_norm", C.c_double)]
+
+
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
 class State(C.Structure):
     _fields_ = [("x", C.c_void_p * 2), ("x_prev", C.c_void_p * 2), ("xi_prev", C.c_void_p), ("xi", C.c_void_p)]
 
@@ -86,6 +99,7 @@ SYMBOLS = [
     ("c8_set_kernel_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_status", C.c_int, [C.c_void_p]),
+    ("c8_lbfgs_minimize", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), OBJECTIVE_FN, C.c_void_p, C.POINTER(LbfgsOpts), C.POINTER(LbfgsResult)]),
     ("c8_set_qoi_avg_disp", C.c_int, [C.c_void_p]),
     ("c8_set_qoi_calibration", C.c_int, [C.c_void_p, C.POINTER(CalibrationDesc)]),
     ("c8_set_measured", C.c_int, [C.c_void_p, C.c_void_p, C.c_double]),

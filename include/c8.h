@@ -250,6 +250,26 @@ int c8_brick_mesh(int nx, int ny, int nz, double lx, double ly, double lz, doubl
 /* Block partition px*py*pz of that brick: part id per element (host array). */
 int c8_brick_partition(int nx, int ny, int nz, int px, int py, int pz, int32_t* elem_part);
 
+/* ---- outer optimiser: bound-constrained L-BFGS on the canonical variables, with the controls of
+ * the reference's ROL set-up (main_inverse.cpp:21-28, :83-120: secant storage, iteration limit, gradient and step
+ * tolerances, function evaluations per line search).  HOST arrays; `fn` returns 0, or non-zero when the objective
+ * cannot be evaluated at x (the line search then shortens the step). */
+typedef int (*c8_objective_fn)(void* user, int n, const double* x, double* f, double* grad);
+typedef struct {
+  int32_t max_iters;      /* "iteration limit" (20) */
+  double grad_tol;        /* "gradient tolerance" (1e-12), on the projected gradient */
+  double step_tol;        /* "step tolerance" (1e-12) */
+  int32_t max_ls_evals;   /* "max line search evals" (5) */
+  int32_t memory;         /* secant storage (20) */
+} c8_lbfgs_opts;
+enum { C8_LBFGS_ITERATION_LIMIT = 0, C8_LBFGS_GRADIENT_TOL = 1, C8_LBFGS_STEP_TOL = 2, C8_LBFGS_LINE_SEARCH_FAILED = 3 };
+typedef struct {
+  int32_t iters, evals, status;
+  double f, projected_gradient_norm;
+} c8_lbfgs_result;
+int c8_lbfgs_minimize(int n, double* x, const double* lo, const double* hi, c8_objective_fn fn, void* user,
+                      const c8_lbfgs_opts* opts, c8_lbfgs_result* res);
+
 #ifdef __cplusplus
 }
 #endif

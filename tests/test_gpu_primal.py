@@ -224,3 +224,42 @@ def test_device_synthetic_calibration_objective_and_gradient():
         errs.append(abs((solve(pp, measured).qoi() - solve(pm, measured).qoi()) / (2 * h) - gd))
     assert min(errs) < 1e-7 * abs(gd), (errs, gd)
     assert errs[0] > 10 * min(errs), (errs, gd)  # second-order convergence of the difference quotient is visible
+
+
+def test_device_inverse_problem_recovers_parameters():
+    # the reference's synthetic calibration in small, end to end on the device: measurements from the true
+    # parameters, Calibration objective, adjoint gradients, canonical [-1, 1] variables, bound-constrained L-BFGS
+    import torch
+    from calibr8_amd import Assembler, InverseProblem, PrimalDriver
+    c, conn, sets = brick(3, 4, 2, 1.0, 1.5, 1.0)
+    zero = lambda x, y, z, t: 0.0
+    spec = [(0, 0, sets["xmin"], zero), (0, 1, sets["ymin"], zero), (0, 2, sets["zmin"], zero),
+            (0, 1, sets["ymax"], lambda x, y, z, t: 0.002 * t)]
+    xmax = set(sets["xmax"].tolist())
+    loc = ([0, 1, 2, 3], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7], [4, 5, 6, 7])
+    faces = [[int(e[k]) for k in f] for e in conn for f in loc if all(int(e[k]) in xmax for k in f)]
+    nsteps, truth = 3, np.array(J2)
+    measured = [None]
+
+    def make_primal(params):
+        asm = Assembler(8, c, conn, "small_J2", params)
+        asm.set_qoi_calibration(faces, weights=(1.0, 1.0, 1.0), balance=1e-2, coord_idx=1, coord_value=0.0,
+                                coord_tol=1e-8, comp=1, dt_over_T=1.0 / nsteps)
+        pr = PrimalDriver(asm, spec, max_iters=20, abs_tol=1e-12, rel_tol=1e-12).solve(nsteps)
+        if measured[0] is not None:
+            pr.set_measured(*measured[0])
+        return pr
+
+    pt = make_primal(truth)
+    loads, zm = [0.0], torch.zeros_like(pt.u[1])
+    for s in range(1, nsteps + 1):
+        pt.asm.set_measured(zm, 0.0)
+        loads.append(pt.asm.qoi_preprocess(pt.u[s], pt.p[s], pt.u[s - 1], pt.p[s - 1], pt.xi[s - 1], pt.xi[s])[1])
+    measured[0] = ([None] + [u.clone() for u in pt.u[1:]], loads)
+    active = [2, 3]  # hardening modulus K and yield strength Y (small_J2.cpp:70-75)
+    inv = InverseProblem(make_primal, truth, active, bounds=[[50.0, 200.0], [1.0, 4.0]])
+    start = np.array([150.0, 3.0])
+    J_start = inv.value_and_gradient(inv.to_canonical(start))[0]
+    found, info = inv.solve(start, max_iters=40, grad_tol=1e-14, step_tol=1e-12, max_ls_evals=8)
+    assert info["f"] < 1e-8 * J_start, (info, J_start)
+    assert np.abs(found / truth[active] - 1.0).max() < 1e-3, (found, info)
