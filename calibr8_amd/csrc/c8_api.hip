@@ -41,6 +41,7 @@ static int model_id(char const* name, int* nloc, int* nparams) {
   if (s == "elastic") { *nloc = Elastic<double>::NLOC; *nparams = Elastic<double>::NPARAMS; return MODEL_ELASTIC; }
   if (s == "small_J2") { *nloc = SmallJ2<double>::NLOC; *nparams = SmallJ2<double>::NPARAMS; return MODEL_SMALL_J2; }
   if (s == "hyper_J2") { *nloc = HyperJ2<double>::NLOC; *nparams = HyperJ2<double>::NPARAMS; return MODEL_HYPER_J2; }
+  if (s == "small_hill") { *nloc = SmallHill<double>::NLOC; *nparams = SmallHill<double>::NPARAMS; return MODEL_SMALL_HILL; }
   return MODEL_NONE;
 }
 

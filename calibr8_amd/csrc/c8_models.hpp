@@ -130,6 +130,71 @@ template <class T> struct SmallJ2 {
   }
 };
 
+// ---- small_hill.cpp (Hill's anisotropic yield function, yield_functions.hpp:34-99; Voce hardening) ---------
+template <class T> struct SmallHill {
+  static constexpr int NLOC = 7, NPARAMS = 11;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (small_hill.cpp:78-88)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD void initial_guess(PointState<T> const&) {  // :143-151
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(xi_prev[k]));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :284-295
+    T const mu = compute_mu(params[0], params[1]);
+    Tens3<T> const eps = small_strain(g.grad_u);
+    Tens3<T> const pstrain = sym6(xi);
+    return scale(2. * mu, dev(eps) - pstrain);
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :271-281
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :298-306
+    return compute_kappa(params[0], params[1]) * trace(small_strain(g.grad_u));
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :196-268
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[9], D = params[10];
+    auto inv2 = [](T const& r) { return 1. / (r * r); };
+    T const i00 = inv2(params[3]), i11 = inv2(params[4]), i22 = inv2(params[5]);
+    T const F = 0.5 * (i11 + i22 - i00), G = 0.5 * (i22 + i00 - i11), H = 0.5 * (i00 + i11 - i22);  // compute_hill_params
+    T const L = 1.5 * inv2(params[8]), M = 1.5 * inv2(params[7]), N = 1.5 * inv2(params[6]);
+    T const alpha = xi[6], alpha_old = xi_prev[6];
+    Tens3<T> const s = dev_cauchy(g);
+    T const d12 = s.yy - s.zz, d20 = s.zz - s.xx, d01 = s.xx - s.yy;
+    T const hill = c8_sqrt(F * d12 * d12 + G * d20 * d20 + H * d01 * d01 +
+                           2. * (L * s.yz * s.yz + M * s.xz * s.xz + N * s.xy * s.xy));  // compute_hill_value
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      Tens3<T> n;  // compute_hill_normal
+      n.xx = ((G + H) * s.xx - H * s.yy - G * s.zz) / hill;
+      n.yy = ((F + H) * s.yy - H * s.xx - F * s.zz) / hill;
+      n.zz = ((G + F) * s.zz - G * s.xx - F * s.yy) / hill;
+      n.xy = n.yx = N * s.xy / hill;
+      n.xz = n.zx = M * s.xz / hill;
+      n.yz = n.zy = L * s.yz / hill;
+      T const dgam = alpha - alpha_old;
+      Tens3<T> const ps = sym6(xi);
+      Tens3<T> Rp = ps - sym6(xi_prev) - scale(dgam, n);
+      Rp.zz = trace(ps);  // the (2,2) equation is replaced by plastic incompressibility (:236)
+      pack_sym6(Rp, R);
+      R[6] = f;
+    } else {
+      C8_UNROLL
+      for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
+    }
+    return path;
+  }
+};
+
 // ---- hyper_J2.cpp -------------------------------------------------------------
 template <class T> struct HyperJ2 {
   static constexpr int NLOC = 8, NPARAMS = 8;

@@ -866,6 +866,100 @@ template <class T> struct SmallJ2 : Local<T> {
   T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
 };
 
+// small_hill.cpp (pstrain SYM_TENSOR, alpha SCALAR; params E nu Y R00 R11 R22 R01 R02 R12 S D);
+// Hill's yield function and its normal: yield_functions.hpp:34-99
+template <class T> struct SmallHill : Local<T> {
+  SmallHill() { this->nres = 2; this->neq[0] = 6; this->neq[1] = 1; this->finish_layout(); }
+  int num_params() const override { return 11; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 7; ++k) xi_pt[k] = 0.; }
+  bool is_finite_deformation() const override { return false; }
+  int solve_nonlinear(Global<T>& g) override {  // :137-190
+    if (std::is_same<T, double>::value) return 0;
+    {
+      Tens<T> const pstrain_old = this->sym_tensor_xi_prev(0);
+      T const alpha_old = this->scalar_xi_prev(1);
+      this->set_sym_tensor_xi_val(0, pstrain_old);
+      this->set_scalar_xi_val(1, val(alpha_old));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :196-268
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2];
+    T const R00 = this->params[3], R11 = this->params[4], R22 = this->params[5];
+    T const R01 = this->params[6], R02 = this->params[7], R12 = this->params[8];
+    T const S = this->params[9], D = this->params[10];
+    T const mu = compute_mu(E, nu);
+    auto inv2 = [](T const& r) { return 1. / (r * r); };  // std::pow(r, -2)
+    T hp[6];  // compute_hill_params
+    hp[0] = 0.5 * (inv2(R11) + inv2(R22) - inv2(R00));
+    hp[1] = 0.5 * (inv2(R22) + inv2(R00) - inv2(R11));
+    hp[2] = 0.5 * (inv2(R00) + inv2(R11) - inv2(R22));
+    hp[3] = 1.5 * inv2(R12);
+    hp[4] = 1.5 * inv2(R02);
+    hp[5] = 1.5 * inv2(R01);
+    Tens<T> const pstrain_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    Tens<T> const s = this->dev_cauchy(g);
+    T const d12 = s(1, 1) - s(2, 2), d20 = s(2, 2) - s(0, 0), d01 = s(0, 0) - s(1, 1);
+    T const hill = sqrt(hp[0] * d12 * d12 + hp[1] * d20 * d20 + hp[2] * d01 * d01 +
+                        2. * (hp[3] * s(1, 2) * s(1, 2) + hp[4] * s(0, 2) * s(0, 2) + hp[5] * s(0, 1) * s(0, 1)));
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    Tens<T> R_pstrain;
+    T R_alpha;
+    if (plastic) {
+      Tens<T> n;  // compute_hill_normal
+      n(0, 0) = (hp[1] + hp[2]) * s(0, 0) - hp[2] * s(1, 1) - hp[1] * s(2, 2);
+      n(1, 1) = (hp[0] + hp[2]) * s(1, 1) - hp[2] * s(0, 0) - hp[0] * s(2, 2);
+      n(2, 2) = (hp[1] + hp[0]) * s(2, 2) - hp[1] * s(0, 0) - hp[0] * s(1, 1);
+      n(0, 1) = hp[5] * s(0, 1); n(0, 2) = hp[4] * s(0, 2); n(1, 2) = hp[3] * s(1, 2);
+      n(1, 0) = n(0, 1); n(2, 0) = n(0, 2); n(2, 1) = n(1, 2);
+      n = n / hill;
+      T const dgam = alpha - alpha_old;
+      R_pstrain = pstrain - pstrain_old - dgam * n;
+      R_pstrain(2, 2) = trace(pstrain);
+      R_alpha = f;
+    } else {
+      R_pstrain = pstrain - pstrain_old;
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_pstrain);
+    this->set_scalar_R(1, R_alpha);
+    return path;
+  }
+  Tens<T> cauchy(Global<T>& g) override {  // :271-281
+    T const p = g.scalar_x(1);
+    return this->dev_cauchy(g) - p * eye<T>();
+  }
+  Tens<T> dev_cauchy(Global<T>& g) override {  // :284-295
+    Tens<T> const I = eye<T>();
+    T const mu = compute_mu(this->params[0], this->params[1]);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    Tens<T> const dev_eps = eps - (trace(eps) / 3.) * I;
+    return (2. * mu) * (dev_eps - pstrain);
+  }
+  T hydro_cauchy(Global<T>& g) override {  // :298-306
+    T const kappa = compute_kappa(this->params[0], this->params[1]);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    return kappa * trace(eps);
+  }
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
 // hyper_J2.cpp (zeta SYM_TENSOR, Ie SCALAR, alpha SCALAR; params E nu Y S D A n K)
 template <class T> struct HyperJ2 : Local<T> {
   HyperJ2() { this->nres = 3; this->neq[0] = 6; this->neq[1] = 1; this->neq[2] = 1; this->finish_layout(); }
@@ -1025,6 +1119,7 @@ template <class T> Local<T>* make_local(std::string const& type) {  // local_res
   if (type == "elastic") return new Elastic<T>();
   if (type == "small_J2") return new SmallJ2<T>();
   if (type == "hyper_J2") return new HyperJ2<T>();
+  if (type == "small_hill") return new SmallHill<T>();
   return nullptr;
 }
 

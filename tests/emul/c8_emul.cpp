@@ -140,6 +140,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     if (model == "elastic") run_wave_adjoint<Elastic>(c);
     else if (model == "small_J2") run_wave_adjoint<SmallJ2>(c);
     else if (model == "hyper_J2") run_wave_adjoint<HyperJ2>(c);
+    else if (model == "small_hill") run_wave_adjoint<SmallHill>(c);
     else return -2;
     return 0;
   }
@@ -148,12 +149,14 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     if (model == "elastic") run_wave<Elastic>(c);
     else if (model == "small_J2") run_wave<SmallJ2>(c);
     else if (model == "hyper_J2") run_wave<HyperJ2>(c);
+    else if (model == "small_hill") run_wave<SmallHill>(c);
     else return -2;
     return 0;
   }
   if (model == "elastic") run<E, Elastic>(c);
   else if (model == "small_J2") run<E, SmallJ2>(c);
   else if (model == "hyper_J2") run<E, HyperJ2>(c);
+  else if (model == "small_hill") run<E, SmallHill>(c);
   else return -2;
   return 0;
 }
