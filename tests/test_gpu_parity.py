@@ -308,3 +308,74 @@ def test_calibration_objective_matches_oracle(kind):
     errs["g"], errs["f"], errs["phi"] = rel_vec(gg, go), rel_vec(fg, fo), rel_vec(phg, pho)
     errs["grad"] = float(np.abs(grg - gro).max() / np.abs(gro).max())
     assert max(errs.values()) < TOL, errs
+
+
+def test_full_size_million_elements_properties():
+    # BASELINE.json's full size (100^3 hex8 = 1 M elements, 4.4e8 non-zeros) through size-independent properties,
+    # all on the device:
+    #  (1) the three scatter modes agree to rounding and the staged mode is bitwise reproducible,
+    #  (2) global equilibrium: the nodal internal forces sum to zero in every direction (partition of unity),
+    #  (3) rigid translations: R unchanged, and J t = 0 for a constant displacement field t,
+    #  (4) J v equals a directional finite difference of R at an all-plastic state.
+    import torch
+    from calibr8_amd import Assembler, brick_mesh
+    n = 100
+    coords, conn = brick_mesh(n, n, n)
+    asm = Assembler(8, coords, conn, "small_J2", J2, scatter="atomic")
+    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)  # the bench state: about half of the points plastic
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    xi0 = asm.new_state()
+
+    def assemble(mode, uu=u, pp=p):
+        asm.set_scatter(mode)
+        ls, xi = asm.new_linsys(), asm.new_state()
+        assert asm.forward_jacobian(uu, pp, z, zp, xi0, xi, ls) == 0
+        return ls, xi
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+
+    la, xa = assemble("atomic")
+    lg, xg = assemble("gather")
+    lg2, _ = assemble("gather")
+    assert torch.equal(lg.flat, lg2.flat) and torch.equal(xa, xg)
+    assert rel(lg.flat, la.flat) < 1e-13
+    del lg2
+    lc, _ = assemble("colored")
+    assert rel(lc.flat, la.flat) < 1e-13
+    del lc, lg
+    frac = float((xa[:, :, 6] > 0).double().mean())
+    assert 0.3 < frac < 0.7
+    # (2)
+    Ru = la.b[0].view(-1, 3)
+    assert float(Ru.sum(0).abs().max()) < 1e-9 * float(Ru.abs().sum())
+    # (3)
+    shift = torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=u.device).repeat(len(p))
+    lt, _ = assemble("atomic", u + shift)
+    # nodal differences of 4e-5 (strain 4e-3 x edge 1e-2) taken from values of 0.3: 1e-16 * 0.3 / 4e-5 ~ 1e-12 of
+    # cancellation in the strains, so the bar here is 1e-10, not the parity bar
+    assert rel(lt.b[0], la.b[0]) < 1e-10 and rel(lt.A[0][0], la.A[0][0]) < 1e-10
+    del lt
+    for k in range(3):
+        t = torch.zeros_like(u).view(-1, 3)
+        t[:, k] = 1.0
+        yu, yp = torch.zeros_like(u), torch.zeros_like(p)
+        asm.apply_A(la, t.view(-1).contiguous(), zp, yu, yp)
+        scale = float(la.A[0][0].abs().max())
+        assert float(yu.abs().max()) < 1e-10 * scale and float(yp.abs().max()) < 1e-10 * scale
+    # (4)
+    up_h, pp_h = prescribed_fields(coords, 0.008, ramp=False, perturb=1e-3)
+    up, pp = asm.dev(up_h), asm.dev(pp_h)
+    lq, xq = assemble("atomic", up, pp)
+    assert bool((xq[:, :, 6] > 0).all())
+    g = torch.Generator(device="cpu").manual_seed(5)
+    v = torch.randn(len(u_h), generator=g, dtype=torch.float64).to(u.device)
+    v /= v.abs().max()
+    h = 1e-7
+    lp, _ = assemble("atomic", up + h * v, pp)
+    lm, _ = assemble("atomic", up - h * v, pp)
+    fd_u, fd_p = (lp.b[0] - lm.b[0]) / (2 * h), (lp.b[1] - lm.b[1]) / (2 * h)
+    yu, yp = torch.zeros_like(u), torch.zeros_like(p)
+    asm.apply_A(lq, v, zp, yu, yp)
+    assert rel(fd_u, yu) < 1e-5 and rel(fd_p, yp) < 1e-5
