@@ -42,12 +42,17 @@ template <class E, int NL> struct WaveShared {
   double N[E::NP0][E::NN];
   double dN[E::NP0][E::NN][3];
   double wdv[E::NP0];
-  double M[E::NP0][NLP][NLP + 1];   // dC/dxi per point
+#ifdef C8_EXPERIMENT_SCATTER_ONLY_LEAN
+#define C8_LEAN_DIM(x) 1
+#else
+#define C8_LEAN_DIM(x) (x)
+#endif
+  double M[C8_LEAN_DIM(E::NP0)][NLP][NLP + 1];   // dC/dxi per point
   double q[E::NP0][WQ];             // interpolated values
   double qprev[E::NP0][9];          // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
   double xip[E::NP0][NLP];          // previous local state
-  double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
+  double D[C8_LEAN_DIM(4)][C8_LEAN_DIM(WF)][WQ + 1];          // dflux/dq of the 4 points of a pass
   double F[E::NP0][WQ];             // flux values
   double gh[E::NP0][NLP];           // adjoint: local history g at each point
   double rq[4][WQ + 1];             // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
@@ -230,7 +235,9 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
   ex.sync();
 
   C8_STAMP(1);
-#ifdef C8_EXPERIMENT_SCATTER_ONLY  // timing experiment only: loads and adds, no arithmetic
+#if defined(C8_EXPERIMENT_SCATTER_ONLY_LEAN)  // timing experiment only: the arithmetic is not even compiled, so
+  if (false) {                                //   the kernel needs few registers and runs at full occupancy
+#elif defined(C8_EXPERIMENT_SCATTER_ONLY)     // timing experiment only: loads and adds, arithmetic compiled but skipped
   if (sa.atomic == 12345) {
 #else
   {
