@@ -56,8 +56,16 @@ template <class Lane> struct GpuExec {
 // (blocks b and b+8 share an XCD, MI355X_MICROARCH.md), so give each XCD one contiguous
 // chunk of the element order: neighbouring elements then meet in the same L2.
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
+#if defined(C8_EXPERIMENT_NO_XCD_REMAP)   // timing experiment: blocks in launch order, round-robin over the XCDs
+  return b;
+#elif defined(C8_EXPERIMENT_XCD_STRIPE)   // timing experiment: XCD x takes every 8th stripe of C8_EXPERIMENT_XCD_STRIPE blocks
+  int const S = C8_EXPERIMENT_XCD_STRIPE;
+  int const x = b & 7, k = b >> 3;        // k-th block of XCD x
+  return ((k / S) * 8 + x) * S + (k % S);
+#else
   int const chunk = (nblocks + 7) >> 3;
   return (b & 7) * chunk + (b >> 3);
+#endif
 }
 
 template <class E, template <class> class ModelT>
@@ -90,7 +98,7 @@ static hipError_t launch_forward(LaunchArgs const& a) {
 
 // K1, one wavefront per hex8 element (c8_assemble_wave.hpp); 4 elements per workgroup
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, 2) k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU) k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
                                                                int first, int count, int nblocks) {
   constexpr int WPB = BLOCK / 64;
   using Lane = WaveLane<ModelT>;
@@ -118,7 +126,7 @@ static hipError_t launch_forward_wave(LaunchArgs const& a) {
 }
 
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, 2) k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU) k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
                                                                   SystemArgs sa, int first, int count, int nblocks) {
   constexpr int WPB = BLOCK / 64;
   using Lane = WaveLane<ModelT>;
@@ -146,7 +154,7 @@ static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
 }
 
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, 2) k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
                                                                SystemArgs sa, int first, int count, int nblocks) {
   constexpr int WPB = BLOCK / 64;
   using Lane = WaveLaneA<ModelT>;
@@ -162,7 +170,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_adjoint_local_wave(MeshTables mt, 
 }
 
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, 2) k_param_gradient_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
+__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k_param_gradient_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
   constexpr int WPB = BLOCK / 64;
   using Lane = WaveLaneA<ModelT>;
   __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];

@@ -52,6 +52,9 @@ template <class T> C8_HD Tens3<T> small_strain(Tens3<T> const& g) {
 template <class T> struct Elastic {
   static constexpr int NLOC = 1, NPARAMS = 4;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = false;
+  // wave kernels: 256-thread workgroups per CU that the register budget is set for (2 -> 256 registers, 1 -> 512),
+  // for the two Jacobian kernels and for the local-adjoint / parameter-gradient kernels
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
   T params[NPARAMS];  // E nu cte delta_T
   T xi[NLOC], xi_prev[NLOC], R[NLOC];
   C8_HD static void init_variables(double* xi0) { xi0[0] = 0.; }
@@ -79,6 +82,7 @@ template <class T> struct Elastic {
 template <class T> struct SmallJ2 {
   static constexpr int NLOC = 7, NPARAMS = 6;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
   T params[NPARAMS];  // E nu K Y cte delta_T  (small_J2.cpp:70-75)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
@@ -134,6 +138,7 @@ template <class T> struct SmallJ2 {
 template <class T> struct SmallHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
   T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (small_hill.cpp:78-88)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
@@ -199,6 +204,9 @@ template <class T> struct SmallHill {
 template <class T> struct HyperJ2 {
   static constexpr int NLOC = 8, NPARAMS = 8;
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  // measured on 1 M hex8 elements: at 256 registers the local-adjoint kernel spills 1 KB per lane (32 ms), at 512
+  // registers and half the occupancy it takes 14.8 ms; the Jacobian kernels are faster at 2 workgroups per CU
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
   T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2.cpp:83-90)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // zeta(6), Ie, alpha
   C8_HD static void init_variables(double* xi0) {  // :119-134

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--edge", type=int, default=100)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--scatter", default="atomic")
+    ap.add_argument("--model", default="small_J2", choices=["small_J2", "hyper_J2", "small_hill", "elastic"])
     ap.add_argument("--tet", action="store_true", help="split every hex into 6 tet4 (the reference's element type)")
     args = ap.parse_args()
     import torch
@@ -34,8 +35,10 @@ def main():
         vol = np.einsum("ij,ij->i", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0])
         assert (vol > 0).all()
         et = 4
-    asm = Assembler(et, coords, conn, "small_J2", J2, scatter=args.scatter)
-    asm.set_active(0, [0, 1, 2, 3])
+    from parity_cases import ACTIVE, EL, HILL, HJ2
+    params = {"small_J2": J2, "hyper_J2": HJ2, "small_hill": HILL, "elastic": EL}[args.model]
+    asm = Assembler(et, coords, conn, args.model, params, scatter=args.scatter)
+    asm.set_active(0, ACTIVE[args.model][:4])
     asm.set_async(True)
     u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
     u, p = asm.dev(u_h), asm.dev(p_h)
@@ -46,7 +49,7 @@ def main():
     f = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=asm.device)
     phi = torch.zeros_like(g)
     z_u, z_p = torch.randn_like(u) * 1e-3, torch.randn_like(p) * 1e-3
-    grad = torch.zeros(4, dtype=torch.float64, device=asm.device)
+    grad = torch.zeros(len(ACTIVE[args.model][:4]), dtype=torch.float64, device=asm.device)
     J = torch.zeros(1, dtype=torch.float64, device=asm.device)
 
     def timeit(fn):
@@ -76,7 +79,7 @@ def main():
     asm.set_kernel("auto")
     res["residual"] = timeit(lambda: asm.global_residual(u, p, u0, p0, xi0, xi, ls))
     res["eval_qoi"] = timeit(lambda: asm.eval_qoi(u, p, J))
-    out = {"elements": asm.nelems, "element_type": "tet4" if args.tet else "hex8", "scatter": args.scatter,
+    out = {"elements": asm.nelems, "element_type": "tet4" if args.tet else "hex8", "model": args.model, "scatter": args.scatter,
            "ms": res, "Melem_per_s": {k: asm.nelems / v / 1e3 for k, v in res.items()}}
     print(json.dumps(out))
 
