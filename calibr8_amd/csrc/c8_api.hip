@@ -192,7 +192,6 @@ int c8_set_stream(c8_ctx* c, void* s) {
 int c8_set_scatter_mode(c8_ctx* c, int mode) {
   if (!c || (mode != C8_SCATTER_ATOMIC && mode != C8_SCATTER_COLORED && mode != C8_SCATTER_GATHER)) return fail(C8_ERR_ARG, "c8_set_scatter_mode: bad argument");
   if (mode == C8_SCATTER_GATHER) {
-    if (!c->ks.gather_rows) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: staged (gather) assembly needs hex8 elements");
     if (c->graph.max_degree > c8::GATHER_MAX_DEGREE) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: node degree too large for staged (gather) assembly");
   }
   c->scatter_mode = mode;
@@ -293,12 +292,13 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
 #endif
   if (c->subset && scatters && c->scatter_mode != C8_SCATTER_ATOMIC)
     return fail(C8_ERR_ARG, std::string(what) + ": element subsets need C8_SCATTER_ATOMIC");
-  // staged assembly: the two Jacobian assemblies through their wave kernels; everything else (residual-only
-  // assembly: 32 adds per element) keeps atomic adds
+  // staged assembly: the two Jacobian assemblies; everything else (residual-only assembly: NDOF adds per element)
+  // keeps atomic adds
   bool const staged = scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] &&
-                      (fn == c->ks.forward_jacobian_wave || fn == c->ks.adjoint_jacobian_wave);
+                      (fn == c->ks.forward_jacobian_wave || fn == c->ks.adjoint_jacobian_wave || fn == c->ks.forward_jacobian ||
+                       (fn == c->ks.adjoint_jacobian && c->ks.adjoint_slot_stages));
   if (scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !staged)
-    return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly needs the wave-per-element kernels");
+    return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly of hex8 adjoint Jacobians needs the wave-per-element kernel");
   if (staged) return run_staged(c, fn, fa, aa, sa);
   LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
   if (c->subset) {

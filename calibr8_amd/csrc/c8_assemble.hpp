@@ -93,7 +93,11 @@ struct GatherArgs {
   double* A[2][2];
   double* b[2];
 };
-template <class E> constexpr int stage_stride() { return E::NDOF * E::NDOF + E::NDOF; }
+// stage[e]: for every element node n the four rows (u_0, u_1, u_2, p) of that node, NDOF columns each, in element
+// DOF order -- the 4*NDOF values a node's row sum needs from this element are contiguous -- then the NDOF entries of
+// the element residual.
+template <class E> constexpr int stage_stride() { return E::NN * 4 * E::NDOF + E::NDOF; }
+template <class E> C8_HD int stage_row(int n, int rr) { return (n * 4 + rr) * E::NDOF; }  // rr: 0..2 = u_rr, 3 = p
 constexpr int GATHER_MAX_DEGREE = 64;  // node-graph rows the gather kernel's LDS accumulator can hold
 
 // ---- per-group shared scratch (LDS) -------------------------------------------
@@ -373,6 +377,19 @@ C8_HD void accumulate_coupled(SH const& sh, int pt, int k, MechFlux<Dual> const&
 // by 64 bytes of positions per element.  If `transpose`, lane k holds ROW k.
 template <class E, class EX, class SH, class GetJ>
 C8_HD void scatter_lhs(EX& ex, SH const& sh, MeshTables const& mt, SystemArgs const& sa, int e, bool transpose, GetJ getj) {
+  if (sa.stage && !transpose) {  // staged assembly: column k of the element matrix into the element's stage
+    ex.each([&](int k) {
+      double const* Jc = getj(k);
+      double* const st = sa.stage + (size_t)(e % sa.stage_ring) * stage_stride<E>();
+      C8_UNROLL
+      for (int a = 0; a < E::NDOF; ++a) {
+        int ia, na, eqa;
+        slot_to_dof<E>(a, ia, na, eqa);
+        st[stage_row<E>(na, ia == 0 ? eqa : 3) + k] = Jc[a];
+      }
+    });
+    return;
+  }
   ex.each([&](int k) {
     double const* Jc = getj(k);
     int ik, nk, eqk;
@@ -394,13 +411,20 @@ C8_HD void scatter_lhs(EX& ex, SH const& sh, MeshTables const& mt, SystemArgs co
         off = (size_t)sh.nptr[nk] * (neqk * neqa) + (size_t)eqk * sh.deg[nk] * neqa + (size_t)pka * neqa + eqa;
         vals = sa.A[ik][ia];
       }
+#ifdef C8_EXPERIMENT_NO_SCATTER  // timing experiment only
+      if (Jc[a] == 1.2345e300)
+#endif
       ex.add(vals + off, Jc[a], sa.atomic);
     }
   });
 }
 
 template <class E, class EX, class SH, class GetR>
-C8_HD void scatter_rhs(EX& ex, SH const& sh, SystemArgs const& sa, GetR getr) {
+C8_HD void scatter_rhs(EX& ex, SH const& sh, SystemArgs const& sa, GetR getr, int e = -1) {
+  if (sa.stage && e >= 0) {  // staged assembly: the element residual behind the element matrix
+    ex.each([&](int k) { sa.stage[(size_t)(e % sa.stage_ring) * stage_stride<E>() + E::NN * 4 * E::NDOF + k] = getr(k); });
+    return;
+  }
   ex.each([&](int k) {
     int ik, nk, eqk;
     slot_to_dof<E>(k, ik, nk, eqk);
@@ -538,7 +562,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
   }
   ex.sync();
   scatter_lhs<E>(ex, sh, mt, sa, e, false, [&](int k) { return ex.lane(k).Jcol; });
-  scatter_rhs<E>(ex, sh, sa, [&](int k) { return ex.lane(k).Rk; });
+  scatter_rhs<E>(ex, sh, sa, [&](int k) { return ex.lane(k).Rk; }, e);
   ex.each([&](int k) {
     if (k == 0 && ex.lane(k).failed) ex.flag(sa.status);
   });

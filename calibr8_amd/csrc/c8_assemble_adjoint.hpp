@@ -254,7 +254,7 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
   } else {
     scatter_lhs<E>(ex, sh, mt, sa, e, true, [&](int k) { return ex.lane(k).Jcol; });
   }
-  scatter_rhs<E>(ex, sh, sa, [&](int k) { return ex.lane(k).rhs; });
+  scatter_rhs<E>(ex, sh, sa, [&](int k) { return ex.lane(k).rhs; }, e);
   ex.each([&](int k) {
     if (k == 0 && ex.lane(k).failed) ex.flag(sa.status);
   });

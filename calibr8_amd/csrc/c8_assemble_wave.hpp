@@ -528,11 +528,14 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
 #ifdef C8_EXPERIMENT_NO_SCATTER  // timing experiment only: everything but the adds
     if (r.J[0] == 1.2345e300) scatter_all(std::integral_constant<int, 1>{});
 #else
-    if (sa.stage) {  // staged assembly: registers -> stage[e] as they stand, 512 contiguous bytes per store
+    if (sa.stage) {  // staged assembly: registers -> stage[e]
       double* const st = sa.stage + (size_t)(e % sa.stage_ring) * stage_stride<E>();
       C8_UNROLL
-      for (int a = 0; a < 16; ++a) st[a * 64 + lane] = r.J[a];
-      if (g == 0) st[E::NDOF * E::NDOF + b] = r.R;
+      for (int n = 0; n < E::NN; ++n) {  // two runs of 32 contiguous values per store
+        st[stage_row<E>(n, 2 * g) + b] = r.J[2 * n];            // row u_2g of node n
+        st[stage_row<E>(n, g ? 3 : 1) + b] = r.J[2 * n + 1];    // row p or u_1
+      }
+      if (g == 0) st[E::NN * 4 * E::NDOF + b] = r.R;
     } else if (sa.atomic) {
 #ifdef C8_EXPERIMENT_SKIP_PCOL  // timing experiment only: no adds into the p columns (blocks (0,1) and (1,1))
       if (b < 3 * E::NN)
@@ -548,28 +551,29 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
 }
 
 // ---- staged assembly, second half: the rows of one node summed over the node's elements ---------------------
-// One wavefront per node.  stage[e][(2n + entry) * 64 + lane] holds, for lane = (g, b), column b of row
-// (n, u_2g) [entry 0] and of row (n, u_1) or (n, p) [entry 1] (wave_scatter's register layout).  The wave
-// adds the contributions of the node's elements, in ascending element order, into acc[pos][row][col] (LDS:
-// pos = position of the column node in this node's graph row) and then adds the finished rows to the four
-// CSR blocks and the node's residual entries to b with contiguous accesses.
+// One wavefront per node, any element type.  stage[e] holds, per element node, that node's four rows (u_0, u_1,
+// u_2, p; NDOF columns each) contiguously (stage_row).  The wave adds the contributions of the node's elements,
+// in ascending element order, into acc[pos][row][col] (LDS: pos = position of the column node in this node's graph
+// row) and then adds the finished rows to the four CSR blocks and the node's residual entries to b with
+// contiguous accesses.
 template <class E, int MAXDEG> struct GatherShared {
   double acc[MAXDEG][16];
 };
 
-template <int MAXDEG> struct GatherLane {
+template <class E, int MAXDEG> struct GatherLane {
   static constexpr int N00 = (9 * MAXDEG + 63) / 64, N01 = (3 * MAXDEG + 63) / 64;
-  double v0[8], v1[8], rv[8];
-  int pos[8];
+  static constexpr int NLD = (4 * E::NDOF + 63) / 64;  // loads per lane and element: hex8 2, tet4 1
+  static constexpr int CH = 8;                         // elements whose rows are in flight together
+  double v[CH][NLD], rv[CH];
+  int pos[CH][NLD];
   double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
   double rsum;
 };
 
 template <class E, int MAXDEG, class EX>
 C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs const& ga, int node) {
-  static_assert(E::NDOF == 32 && E::NN == 8, "staged assembly is implemented for hex8");
-  constexpr int CH = 8;  // elements whose rows are in flight together
-  using GL = GatherLane<MAXDEG>;
+  using GL = GatherLane<E, MAXDEG>;
+  constexpr int CH = GL::CH, NLD = GL::NLD, NB = 4 * E::NDOF;
   int const nptr = ga.nodeptr[node], deg = ga.nodeptr[node + 1] - nptr;
   int const e0 = ga.nodeelem_ptr[node], e1 = ga.nodeelem_ptr[node + 1];
   size_t const np = (size_t)nptr;
@@ -602,20 +606,24 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
     // all loads of the chunk first (independent HBM round trips), then the adds in element order
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
-      int const b = lane & 31;
-      bool const bu = b < 3 * E::NN;
-      int const m = bu ? b / 3 : b - 3 * E::NN;
       C8_UNROLL
       for (int k = 0; k < CH; ++k) {
-        r.pos[k] = -1;
         if (c0 + k < e1) {
           int const packed = ga.nodeelem[c0 + k];
           int const e = packed >> 3, ln = packed & 7;
           double const* const st = ga.stage + (size_t)(e % ga.stage_ring) * stage_stride<E>();
-          r.pos[k] = ga.pos[((size_t)e * E::NN + m) * E::NN + ln];
-          r.v0[k] = st[(2 * ln) * 64 + lane];
-          r.v1[k] = st[(2 * ln + 1) * 64 + lane];
-          r.rv[k] = (lane < 4) ? st[E::NDOF * E::NDOF + (lane < 3 ? 3 * ln + lane : 3 * E::NN + ln)] : 0.;
+          C8_UNROLL
+          for (int j = 0; j < NLD; ++j) {
+            int const idx = lane + 64 * j;  // (row rr, column c) of the node's block: idx = rr * NDOF + c
+            r.pos[k][j] = -1;
+            if (idx < NB) {
+              int const c = idx % E::NDOF;
+              int const m = c < 3 * E::NN ? c / 3 : c - 3 * E::NN;
+              r.pos[k][j] = ga.pos[((size_t)e * E::NN + m) * E::NN + ln];
+              r.v[k][j] = st[stage_row<E>(ln, 0) + idx];
+            }
+          }
+          r.rv[k] = (lane < 4) ? st[E::NN * 4 * E::NDOF + (lane < 3 ? 3 * ln + lane : 3 * E::NN + ln)] : 0.;
         }
       }
     });
@@ -624,10 +632,15 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
       if (c0 + k >= e1) break;
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
-        int const b = lane & 31, g = lane >> 5;
-        int const col = (b < 3 * E::NN) ? b % 3 : 3;
-        sh.acc[r.pos[k]][(2 * g) * 4 + col] += r.v0[k];         // row u_2g
-        sh.acc[r.pos[k]][(g ? 3 : 1) * 4 + col] += r.v1[k];     // row p or u_1
+        C8_UNROLL
+        for (int j = 0; j < NLD; ++j) {
+          int const idx = lane + 64 * j;
+          if (idx < NB) {
+            int const rr = idx / E::NDOF, c = idx % E::NDOF;
+            int const col = c < 3 * E::NN ? c % 3 : 3;
+            sh.acc[r.pos[k][j]][rr * 4 + col] += r.v[k][j];  // distinct addresses within one instruction
+          }
+        }
         r.rsum += r.rv[k];
       });
       ex.sync();
@@ -659,7 +672,6 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
   });
   ex.sync();
 }
-
 
 template <class E, template <class> class ModelT, class EX>
 C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,

@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(BLOCK) k_gather_rows(GatherArgs ga, int first,
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
   if (gi >= count) return;
-  GatherLane<MAXDEG> L;
-  GpuExec<GatherLane<MAXDEG>> ex(lane, L);
+  GatherLane<E, MAXDEG> L;
+  GpuExec<GatherLane<E, MAXDEG>> ex(lane, L);
   gather_node_rows<E, MAXDEG>(ex, shs[wib], ga, ga.node_order[first + gi]);
 }
 template <class E> static hipError_t launch_gather_rows(GatherArgs const& ga, int first, int count, int max_degree, hipStream_t stream) {
@@ -352,16 +352,12 @@ template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get_adjoint() { return nullptr; }
   static LaunchFn get_adjoint_local() { return nullptr; }
   static LaunchFn get_param_gradient() { return nullptr; }
-  static GatherFn get_gather() { return nullptr; }
-  static int stage() { return 0; }
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint() { return &launch_adjoint_jacobian_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint_local() { return &launch_adjoint_local_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_param_gradient() { return &launch_param_gradient_wave<Elem<C8_HEX8>, ModelT>; }
-  static GatherFn get_gather() { return &launch_gather_rows<Elem<C8_HEX8>>; }
-  static int stage() { return stage_stride<Elem<C8_HEX8>>(); }
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
@@ -376,8 +372,9 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;
   ks.param_gradient = &launch_param_gradient<E, ModelT>;
   ks.qoi = &launch_qoi<E, ModelT>;
-  ks.gather_rows = WaveKernel<E, ModelT>::get_gather();
-  ks.stage_stride = WaveKernel<E, ModelT>::stage();
+  ks.gather_rows = &launch_gather_rows<E>;
+  ks.stage_stride = stage_stride<E>();
+  ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements
   return ks;
 }
 

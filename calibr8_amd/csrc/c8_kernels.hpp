@@ -33,8 +33,9 @@ struct KernelSet {
   LaunchFn adjoint_local_wave;     // K4, one wavefront per element (hex8 only, else null)
   LaunchFn param_gradient_wave;    // K5, one wavefront per element (hex8 only, else null)
   LaunchFn qoi;                // K6
-  GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage (hex8 only, else null)
-  int stage_stride;            // doubles per element in the stage (0 when gather_rows is null)
+  GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage
+  int stage_stride;            // doubles per element in the stage
+  bool adjoint_slot_stages;    // the slot-per-lane K3 can store into the stage (it transposes through LDS first)
 };
 
 // registry keyed like the reference's string factories

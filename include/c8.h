@@ -38,9 +38,9 @@ typedef struct c8_ctx c8_ctx;
 enum { C8_ELEM_TET4 = 4, C8_ELEM_HEX8 = 8 };
 enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -3, C8_ERR_UNSUPPORTED = -4 };
 /* ATOMIC: one launch, f64 atomic adds.  COLORED: one launch per element colour, plain adds, reproducible.
- * GATHER (hex8 wave kernels): element matrices are staged element-major in a context-owned buffer
- * (8.4 KB per element) and a second kernel sums each node's rows in ascending element order: no atomics,
- * reproducible, and the fastest of the three on MI355X. */
+ * GATHER: element matrices are staged element-major in a context-owned buffer (8.4 KB per hex8, 2.2 KB per
+ * tet4 element) and a second kernel sums each node's rows in ascending element order: no atomics, bitwise
+ * reproducible; the fastest mode for tet4 meshes. */
 enum { C8_SCATTER_ATOMIC = 0, C8_SCATTER_COLORED = 1, C8_SCATTER_GATHER = 2 };
 enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2 };
 

@@ -48,12 +48,36 @@ struct Call {
   SystemArgs sa;
 };
 
+// staged assembly in the order the chunk loop of c8_api.hip produces: chunk k into the ring, then the rows of the
+// nodes that chunk k completes; a small minimum chunk so that test meshes go round the ring
+template <class E, class Assemble> static void run_staged(Call const& c, Assemble assemble) {
+  StagePlan pl;
+  plan_staged_assembly(*c.mesh, *c.graph, 1, 1, pl);
+  std::vector<double> stage((size_t)pl.ring * stage_stride<E>(), 0.);
+  SystemArgs sa = c.sa;
+  sa.stage = stage.data();
+  sa.stage_ring = pl.ring;
+  auto* gsh = new GatherShared<E, GATHER_MAX_DEGREE>();
+  auto* gex = new CpuExec<GatherLane<E, GATHER_MAX_DEGREE>, 64>();
+  GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), stage.data(), pl.ring,
+                pl.node_order.data(), {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
+  for (int k = 0; k < pl.nchunks; ++k) {
+    int const e1 = std::min(c.nelems, (k + 1) * pl.chunk);
+    for (int e = k * pl.chunk; e < e1; ++e) assemble(sa, e);
+    for (int q = pl.node_off[k]; q < pl.node_off[k + 1]; ++q) gather_node_rows<E, GATHER_MAX_DEGREE>(*gex, *gsh, ga, pl.node_order[q]);
+  }
+  if (c.nchunks_out) *c.nchunks_out = pl.nchunks;
+  delete gex;
+  delete gsh;
+}
+
 template <class E, template <class> class ModelT> static void run(Call const& c) {
   using SH = GroupShared<E, ModelT<Dual>::NLOC>;
   SH sh;
   if (c.what == K_FORWARD) {
     auto* ex = new CpuExec<ForwardLane<E, ModelT>, E::NDOF>();
-    for (int e = 0; e < c.nelems; ++e) forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, c.sa, e);
+    if (c.staged) run_staged<E>(c, [&](SystemArgs const& sa, int e) { forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, sa, e); });
+    else for (int e = 0; e < c.nelems; ++e) forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, c.sa, e);
     delete ex;
   } else if (c.what == K_RESIDUAL) {
     auto* ex = new CpuExec<ResidualLane<E, ModelT>, E::NDOF>();
@@ -61,7 +85,8 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
     delete ex;
   } else if (c.what == K_ADJ_JAC) {
     auto* ex = new CpuExec<AdjointLane<E, ModelT>, E::NDOF>();
-    for (int e = 0; e < c.nelems; ++e) adjoint_jacobian_element<E, ModelT, PointQoi>(*ex, sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+    if (c.staged && E::NDOF <= 16) run_staged<E>(c, [&](SystemArgs const& sa, int e) { adjoint_jacobian_element<E, ModelT, PointQoi>(*ex, sh, c.mt, c.ms, c.fa, c.aa, sa, e); });
+    else for (int e = 0; e < c.nelems; ++e) adjoint_jacobian_element<E, ModelT, PointQoi>(*ex, sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
     delete ex;
   } else if (c.what == K_ADJ_LOCAL) {
     auto* ex = new CpuExec<AdjointLane<E, ModelT>, E::NDOF>();
@@ -100,36 +125,12 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
   auto* ex = new CpuExec<WaveLane<ModelT>, 64>();
-  SystemArgs sa = c.sa;
-  if (!c.staged) {
-    for (int e = 0; e < c.nelems; ++e) {
-      if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
-      else adjoint_jacobian_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
-    }
-  } else {
-    // staged assembly in the order the stream pipeline of c8_api.hip produces: chunk k into the ring, then the
-    // rows of the nodes that chunk k completes; a small minimum chunk so that test meshes go round the ring
-    StagePlan pl;
-    plan_staged_assembly(*c.mesh, *c.graph, 1, 1, pl);
-    std::vector<double> stage((size_t)pl.ring * stage_stride<E>(), 0.);
-    sa.stage = stage.data();
-    sa.stage_ring = pl.ring;
-    auto* gsh = new GatherShared<E, GATHER_MAX_DEGREE>();
-    auto* gex = new CpuExec<GatherLane<GATHER_MAX_DEGREE>, 64>();
-    GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), stage.data(), pl.ring,
-                  pl.node_order.data(), {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
-    for (int k = 0; k < pl.nchunks; ++k) {
-      int const e1 = std::min(c.nelems, (k + 1) * pl.chunk);
-      for (int e = k * pl.chunk; e < e1; ++e) {
-        if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
-        else adjoint_jacobian_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
-      }
-      for (int q = pl.node_off[k]; q < pl.node_off[k + 1]; ++q) gather_node_rows<E, GATHER_MAX_DEGREE>(*gex, *gsh, ga, pl.node_order[q]);
-    }
-    if (c.nchunks_out) *c.nchunks_out = pl.nchunks;
-    delete gex;
-    delete gsh;
-  }
+  auto one = [&](SystemArgs const& sa, int e) {
+    if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
+    else adjoint_jacobian_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
+  };
+  if (c.staged) run_staged<E>(c, one);
+  else for (int e = 0; e < c.nelems; ++e) one(c.sa, e);
   delete ex;
   delete sh;
 }

@@ -61,6 +61,17 @@ def test_staged_gather_assembly(model, params, eps):
     check_adjoint_chain(orc, dut, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("kind", ["tet4", "hex8"])
+def test_staged_gather_assembly_slot_kernels(kind):
+    # staged assembly through the slot-per-lane kernels: tet4 K1 and K3 (transposed through LDS), hex8 K1
+    from parity_cases import J2
+    orc, dut, c = make_pair(factory, kind, "small_J2", J2)
+    dut.staged = True
+    check_forward(orc, dut, c, "small_J2", 0.004, TOL)
+    if kind == "tet4":
+        check_adjoint_chain(orc, dut, c, "small_J2", 0.004, TOL)
+
+
 def test_staged_assembly_goes_round_the_ring():
     # a long thin brick: 16 chunks through a ring of three, node rows summed as their last chunk completes
     import emul_lib

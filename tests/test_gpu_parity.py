@@ -123,6 +123,19 @@ def test_staged_gather_assembly_hex8(model, params, eps):
     check_adjoint_chain(orc, gpu, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_staged_gather_assembly_tet4(model, params, eps):
+    # tet4 (the reference's element type): K1 and K3 of the slot-per-lane kernels into the stage, rows gathered
+    orc, gpu, c = make_pair(factory("gather"), "tet4", model, params)
+    check_forward(orc, gpu, c, model, eps, TOL)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+
+
+def test_staged_gather_slot_kernel_hex8():
+    orc, gpu, c = make_pair(factory("gather", "slot"), "hex8", "small_J2", J2)
+    check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
+
+
 def test_staged_gather_ring_pipeline():
     # small chunks: 20+ chunks through the ring of three, gathers overlapping later chunks on their own stream
     from gpu_backend import GpuBackend
@@ -137,7 +150,7 @@ def test_staged_gather_ring_pipeline():
 
 def test_staged_gather_two_sets_and_reproducible():
     check_two_element_sets(factory("gather", "wave"), "hex8", TOL)
-    # two runs are bitwise identical (fixed summation order); tet4 refuses the mode loudly
+    # two runs are bitwise identical (fixed summation order)
     from gpu_backend import GpuBackend
     from parity_cases import mesh_of
     c, conn = hex_mesh((5, 4, 3))
@@ -153,9 +166,11 @@ def test_staged_gather_two_sets_and_reproducible():
         assert np.array_equal(out[0].b[i], out[1].b[i])
         for j in range(2):
             assert np.array_equal(out[0].A[i][j], out[1].A[i][j])
-    et, ct, connt = mesh_of("tet4")
-    with pytest.raises(RuntimeError, match="hex8"):
-        GpuBackend(et, ct, connt, "small_J2", J2, scatter="gather")
+    # the slot-per-lane adjoint kernel of hex8 cannot stage (it holds rows, not columns): refused loudly
+    gs = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather", kernel="slot")
+    with pytest.raises(RuntimeError, match="wave-per-element"):
+        gs.adjoint_jacobian(u, p, z, zp, gs.new_state(), xi, np.zeros((gs.nelems, gs.npts, gs.nloc)),
+                            np.zeros((gs.nelems, gs.npts, 4 * gs.nn)), gs.new_linsys())
 
 
 @pytest.mark.parametrize("kind,kernel", [("hex8", "wave"), ("hex8", "slot"), ("tet4", "auto")])
