@@ -394,3 +394,43 @@ def test_full_size_million_elements_properties():
     yu, yp = torch.zeros_like(u), torch.zeros_like(p)
     asm.apply_A(lq, v, zp, yu, yp)
     assert rel(fd_u, yu) < 1e-5 and rel(fd_p, yp) < 1e-5
+
+
+def test_full_size_million_tets_properties():
+    # the reference's element type at a million elements (56^3 hexes split into 6 tets each, 1.05 M tet4):
+    # scatter modes agree, staged mode bitwise reproducible, global equilibrium, rigid-translation null space
+    import torch
+    from calibr8_amd import Assembler, brick_mesh
+    n = 56
+    coords, hexes = brick_mesh(n, n, n)
+    tets = [[0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6], [0, 5, 1, 6]]  # Kuhn split
+    conn = np.concatenate([hexes[:, t] for t in tets]).astype(np.int32)
+    asm = Assembler(4, coords, conn, "small_J2", J2, scatter="atomic")
+    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    xi0 = asm.new_state()
+
+    def assemble(mode):
+        asm.set_scatter(mode)
+        ls, xi = asm.new_linsys(), asm.new_state()
+        assert asm.forward_jacobian(u, p, z, zp, xi0, xi, ls) == 0
+        return ls, xi
+
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    la, xa = assemble("atomic")
+    lg, xg = assemble("gather")
+    lg2, _ = assemble("gather")
+    lc, _ = assemble("colored")
+    assert torch.equal(lg.flat, lg2.flat) and torch.equal(xa, xg)
+    assert rel(lg.flat, la.flat) < 1e-13 and rel(lc.flat, la.flat) < 1e-13
+    assert 0.3 < float((xa[:, :, 6] > 0).double().mean()) < 0.7
+    Ru = la.b[0].view(-1, 3)
+    assert float(Ru.sum(0).abs().max()) < 1e-9 * float(Ru.abs().sum())
+    for k in range(3):
+        t = torch.zeros_like(u).view(-1, 3)
+        t[:, k] = 1.0
+        yu, yp = torch.zeros_like(u), torch.zeros_like(p)
+        asm.apply_A(la, t.view(-1).contiguous(), zp, yu, yp)
+        scale = float(la.A[0][0].abs().max())
+        assert float(yu.abs().max()) < 1e-10 * scale and float(yp.abs().max()) < 1e-10 * scale
