@@ -65,6 +65,7 @@ template <class E, int NL> struct WaveShared {
 template <template <class> class ModelT> struct WaveLane {
   using Model = ModelT<Dual>;
   Model m;
+  typename Model::Trial trial;
   PointState<Dual> g;
   double b[Model::NLOC];
   double J[16];   // phase P: rows of this lane's half, column b
@@ -278,12 +279,13 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
   });
   if (Model::HAS_LOCAL && !ADJOINT) {
     auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
+    ex.each([&](int lane) { auto& r = ex.lane(lane); r.trial = r.m.trial(r.g); });  // once per point, not per iteration
     while (ex.any(running)) {
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         if (!running(lane)) return;
         int const pt = lane >> 3, d = lane & 7;
-        r.m.evaluate(r.g, ms.abs_tol);
+        r.m.evaluate(r.g, ms.abs_tol, r.trial);
         double nrm = 0.;
         C8_UNROLL
         for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;

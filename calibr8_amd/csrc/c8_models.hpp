@@ -48,6 +48,11 @@ template <class T> C8_HD Tens3<T> small_strain(Tens3<T> const& g) {
   return scale(0.5, g + gt);
 }
 
+// Point quantities of a local model that depend on the global state and the previous local state only, not on the
+// unknowns: a model may compute them once per point (trial) and reuse them over the Newton iterations
+// (evaluate(g, tol, trial)).  Models without such quantities use NoTrial.
+struct NoTrial {};
+
 // ---- elastic.cpp:76-136 -----------------------------------------------------
 template <class T> struct Elastic {
   static constexpr int NLOC = 1, NPARAMS = 4;
@@ -55,6 +60,9 @@ template <class T> struct Elastic {
   // wave kernels: 256-thread workgroups per CU that the register budget is set for (2 -> 256 registers, 1 -> 512),
   // for the two Jacobian kernels and for the local-adjoint / parameter-gradient kernels
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
   T params[NPARAMS];  // E nu cte delta_T
   T xi[NLOC], xi_prev[NLOC], R[NLOC];
   C8_HD static void init_variables(double* xi0) { xi0[0] = 0.; }
@@ -83,6 +91,9 @@ template <class T> struct SmallJ2 {
   static constexpr int NLOC = 7, NPARAMS = 6;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
   T params[NPARAMS];  // E nu K Y cte delta_T  (small_J2.cpp:70-75)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
@@ -139,6 +150,9 @@ template <class T> struct SmallHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
   T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (small_hill.cpp:78-88)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
@@ -253,14 +267,25 @@ template <class T> struct HyperJ2 {
     return (kappa * 0.5) * (J - 1. / J);
   }
   C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
-  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :226-314
+  // the trial elastic left Cauchy-Green tensor depends on F, F_prev and the previous state only (:137-154)
+  struct Trial { T dev_bt[6], tr_bt_3; };
+  C8_HD Trial trial(PointState<T> const& g) const {
+    Tens3<T> const bt = be_bar_trial(g);
+    Trial t;
+    pack_sym6(dev(bt), t.dev_bt);
+    t.tr_bt_3 = trace(bt) / 3.;
+    return t;
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {
+    return evaluate(g, abs_tol, trial(g), force_path, path_in);
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const& tr, bool force_path = false, int path_in = 0) {  // :226-314
     double const sqrt_23 = 0.81649658092772603273;
     double const sqrt_32 = 1.22474487139158904910;
     T const mu = compute_mu(params[0], params[1]);
     T const Y = params[2], S = params[3], D = params[4], A = params[5], nexp = params[6], K = params[7];
     T const Ie = xi[6], alpha = xi[7], alpha_old = xi_prev[7];
     Tens3<T> const zeta = sym6(xi);
-    Tens3<T> const bt = be_bar_trial(g);
     Tens3<T> const s = scale(mu, zeta);
     T const s_mag = norm(s);
     double const power_law_offset = 1e-12;
@@ -269,7 +294,7 @@ template <class T> struct HyperJ2 {
     int path;
     if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
     else path = path_in;
-    Tens3<T> Rz = zeta - dev(bt);
+    Tens3<T> Rz = zeta - sym6(tr.dev_bt);
     if (path == C8_PLASTIC_PATH) {
       T const dgam = sqrt_32 * (alpha - alpha_old);
       T const c = (2. * dgam) * Ie / s_mag;
@@ -279,7 +304,7 @@ template <class T> struct HyperJ2 {
       R[6] = det(be) - 1.;
       R[7] = f;
     } else {
-      R[6] = Ie - trace(bt) / 3.;
+      R[6] = Ie - tr.tr_bt_3;
       R[7] = alpha - alpha_old;
     }
     pack_sym6(Rz, R);
