@@ -357,6 +357,14 @@ int c8_assemble_forward_jacobian_subset(c8_ctx* c, const c8_state* st, const c8_
 int c8_assemble_residual(c8_ctx* c, const c8_state* st, const c8_system* sys) {
   if (!c || !check_state(st) || !sys || !sys->b[0] || !sys->b[1]) return fail(C8_ERR_ARG, "c8_assemble_residual: null argument");
   SystemArgs sa{{{nullptr, nullptr}, {nullptr, nullptr}}, {sys->b[0], sys->b[1]}, nullptr, 0};
+  // hex8, natural element order with atomic adds (whole mesh, not colour-batched): eight elements per wavefront
+  if (c->ks.residual_wave && c->kernel_variant != C8_KERNEL_SLOT && c->scatter_mode != C8_SCATTER_COLORED && !c->subset) {
+    sa.status = c->d_status;
+    sa.atomic = 1;
+    LaunchArgs a{tables(c, false), c->ms, field_args(st), AdjointArgs{}, sa, 0, c->mesh.nelems, c->stream};
+    C8_HIP(c->ks.residual_wave(a));
+    return c->async ? C8_OK : c8_status(c);
+  }
   return run(c, c->ks.residual, field_args(st), AdjointArgs{}, sa, true, "c8_assemble_residual");
 }
 

@@ -956,4 +956,165 @@ template <class EX> C8_HD void param_gradient_wave_flush(EX& ex, AdjointArgs con
   });
 }
 
+// =====================================================================================
+// K2 for hex8, eight elements per wavefront: eval_global_residual (evaluations.cpp:156-259), no AD.
+// The slot-per-lane kernel evaluates every point on all 32 lanes of an element; here lane (element, point)
+// evaluates the constitutive model and the point fluxes once, and lane (element, node) contracts them with the
+// shape-function gradients of its node, rebuilt from the stored inverse Jacobians (9 values per point instead of
+// a 24-value gradient table).  Adds into b are atomic (4 per lane).
+// =====================================================================================
+template <class E> struct ResidualWaveShared {
+  static constexpr int NE = 8;  // elements per wavefront
+  double X[NE][E::NN][3], u[NE][E::NN][3], p[NE][E::NN], u_prev[NE][E::NN][3];
+  double Ji[NE][E::NP0][9];       // (dx/dxi)^-1, row-major: dN/dx_l = sum_a Ji[3l+a] dN/dxi_a
+  double wdv[NE][E::NP0];
+  double F[NE][E::NP0][WF + 1];   // point fluxes, both ip sets fused (same points on hex8)
+  double h[NE];
+  int32_t node[NE][E::NN];
+};
+template <template <class> class ModelT> struct ResidualWaveLane {
+  ModelT<double> m;
+  PointState<double> g;
+};
+
+template <class E, template <class> class ModelT, class EX>
+C8_HD void residual_wave8(EX& ex, ResidualWaveShared<E>& sh, MeshTables const& mt, ModelSettings const& ms,
+                          FieldArgs const& fa, SystemArgs const& sa, int e0, int count) {
+  using Model = ModelT<double>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  static_assert(E::NN == 8 && E::NP0 == 8 && E::SAME_POINTS, "eight nodes, eight points, one point set");
+  // ---- lane (element, node): nodal data ----
+  ex.each([&](int lane) {
+    int const el = lane >> 3, n = lane & 7;
+    if (el >= count) return;
+    int const node = mt.conn[(size_t)(e0 + el) * E::NN + n];
+    sh.node[el][n] = node;
+    C8_UNROLL
+    for (int d = 0; d < 3; ++d) {
+      sh.X[el][n][d] = mt.coords[(size_t)node * 3 + d];
+      sh.u[el][n][d] = fa.u[(size_t)node * 3 + d];
+      if (PREV) sh.u_prev[el][n][d] = fa.u_prev[(size_t)node * 3 + d];
+    }
+    sh.p[el][n] = fa.p[node];
+  });
+  ex.sync();
+  // ---- lane (element, point): geometry, interpolation, model, fluxes ----
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    if (el >= count) return;
+    auto& r = ex.lane(lane);
+    int const e = e0 + el;
+    double xi[3], w;
+    E::point(0, pt, xi, w);
+    double J[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};           // J(a,b) = dx_b / dxi_a
+    double Gu[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};          // du_i / dxi_a
+    double Gup[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+    double Gp[3] = {0., 0., 0.}, pv = 0., uv[3] = {0., 0., 0.};
+    C8_UNROLL
+    for (int n = 0; n < E::NN; ++n) {
+      double g[3];
+      E::dNdxi(n, xi, g);
+      double const Nn = E::N(n, xi), pn = sh.p[el][n];
+      pv += pn * Nn;
+      C8_UNROLL
+      for (int a = 0; a < 3; ++a) {
+        Gp[a] += pn * g[a];
+        C8_UNROLL
+        for (int b = 0; b < 3; ++b) {
+          J[a][b] += g[a] * sh.X[el][n][b];
+          Gu[b][a] += sh.u[el][n][b] * g[a];
+          if (PREV) Gup[b][a] += sh.u_prev[el][n][b] * g[a];
+        }
+      }
+      C8_UNROLL
+      for (int b = 0; b < 3; ++b) uv[b] += sh.u[el][n][b] * Nn;
+    }
+    Tens3<double> Jt;
+    Jt.xx = J[0][0]; Jt.xy = J[0][1]; Jt.xz = J[0][2];
+    Jt.yx = J[1][0]; Jt.yy = J[1][1]; Jt.yz = J[1][2];
+    Jt.zx = J[2][0]; Jt.zy = J[2][1]; Jt.zz = J[2][2];
+    double const dJ = det(Jt);
+    Tens3<double> const Ji = inverse(Jt);
+    double const ji[9] = {Ji.xx, Ji.xy, Ji.xz, Ji.yx, Ji.yy, Ji.yz, Ji.zx, Ji.zy, Ji.zz};
+    C8_UNROLL
+    for (int q = 0; q < 9; ++q) sh.Ji[el][pt][q] = ji[q];
+    sh.wdv[el][pt] = w * dJ;
+    // d/dx_l = sum_a Ji[3l+a] d/dxi_a
+    auto phys = [&](double const* gx, int l) { return ji[3 * l] * gx[0] + ji[3 * l + 1] * gx[1] + ji[3 * l + 2] * gx[2]; };
+    r.g.grad_u.xx = phys(Gu[0], 0); r.g.grad_u.xy = phys(Gu[0], 1); r.g.grad_u.xz = phys(Gu[0], 2);
+    r.g.grad_u.yx = phys(Gu[1], 0); r.g.grad_u.yy = phys(Gu[1], 1); r.g.grad_u.yz = phys(Gu[1], 2);
+    r.g.grad_u.zx = phys(Gu[2], 0); r.g.grad_u.zy = phys(Gu[2], 1); r.g.grad_u.zz = phys(Gu[2], 2);
+    if (PREV) {
+      r.g.grad_u_prev.xx = phys(Gup[0], 0); r.g.grad_u_prev.xy = phys(Gup[0], 1); r.g.grad_u_prev.xz = phys(Gup[0], 2);
+      r.g.grad_u_prev.yx = phys(Gup[1], 0); r.g.grad_u_prev.yy = phys(Gup[1], 1); r.g.grad_u_prev.yz = phys(Gup[1], 2);
+      r.g.grad_u_prev.zx = phys(Gup[2], 0); r.g.grad_u_prev.zy = phys(Gup[2], 1); r.g.grad_u_prev.zz = phys(Gup[2], 2);
+    } else {
+      r.g.grad_u_prev = scale(0., eye3<double>());
+    }
+    r.g.p = pv;
+    C8_UNROLL
+    for (int l = 0; l < 3; ++l) { r.g.grad_p[l] = phys(Gp, l); r.g.u[l] = uv[l]; }
+    if (pt == 0) {  // mean-square edge length, mechanics.cpp:103-113
+      double hh = 0.;
+      C8_UNROLL
+      for (int ed = 0; ed < E::NEDGES; ++ed) {
+        int a, b;
+        E::edge(ed, a, b);
+        double const dx = sh.X[el][b][0] - sh.X[el][a][0], dy = sh.X[el][b][1] - sh.X[el][a][1], dz = sh.X[el][b][2] - sh.X[el][a][2];
+        hh += dx * dx + dy * dy + dz * dz;
+      }
+      sh.h[el] = sqrt(hh / E::NEDGES);
+    }
+    int const es = mt.elem_set ? mt.elem_set[e] : 0;
+    C8_UNROLL
+    for (int q = 0; q < Model::NPARAMS; ++q) r.m.params[q] = mt.params[es * Model::NPARAMS + q];
+    size_t const qp = ((size_t)e * E::NP0 + pt) * NL;
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) { r.m.xi[j] = fa.xi[qp + j]; r.m.xi_prev[j] = fa.xi_prev[qp + j]; }
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    if (el >= count) return;
+    auto& r = ex.lane(lane);
+    MechFlux<double> f;
+    Mechanics::flux_coupled(r.m, r.g, sh.h[el], ms.stab_mult, f);
+    f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);
+    double* Fp = sh.F[el][pt];
+    Fp[0] = f.Gu.xx; Fp[1] = f.Gu.xy; Fp[2] = f.Gu.xz;
+    Fp[3] = f.Gu.yx; Fp[4] = f.Gu.yy; Fp[5] = f.Gu.yz;
+    Fp[6] = f.Gu.zx; Fp[7] = f.Gu.zy; Fp[8] = f.Gu.zz;
+    Fp[9] = f.Vp;
+    Fp[10] = f.Gp[0]; Fp[11] = f.Gp[1]; Fp[12] = f.Gp[2];
+  });
+  ex.sync();
+  // ---- lane (element, node): R_u[n][i] = sum_pt w dv Gu[i][.] . grad N_n ; R_p[n] likewise (residual_entry) ----
+  ex.each([&](int lane) {
+    int const el = lane >> 3, n = lane & 7;
+    if (el >= count) return;
+    double R[4] = {0., 0., 0., 0.};
+    C8_UNROLL
+    for (int pt = 0; pt < E::NP0; ++pt) {
+      double xi[3], w, g[3];
+      E::point(0, pt, xi, w);
+      E::dNdxi(n, xi, g);
+      double const* ji = sh.Ji[el][pt];
+      double const wdv = sh.wdv[el][pt];
+      double const d0 = (ji[0] * g[0] + ji[1] * g[1] + ji[2] * g[2]) * wdv, d1 = (ji[3] * g[0] + ji[4] * g[1] + ji[5] * g[2]) * wdv,
+                   d2 = (ji[6] * g[0] + ji[7] * g[1] + ji[8] * g[2]) * wdv;
+      double const* Fp = sh.F[el][pt];
+      R[0] += Fp[0] * d0 + Fp[1] * d1 + Fp[2] * d2;
+      R[1] += Fp[3] * d0 + Fp[4] * d1 + Fp[5] * d2;
+      R[2] += Fp[6] * d0 + Fp[7] * d1 + Fp[8] * d2;
+      R[3] += Fp[9] * (E::N(n, xi) * wdv) + Fp[10] * d0 + Fp[11] * d1 + Fp[12] * d2;
+    }
+    int const node = sh.node[el][n];
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i) ex.add(sa.b[0] + (size_t)node * 3 + i, R[i], 1);
+    ex.add(sa.b[1] + node, R[3], 1);
+  });
+  ex.sync();
+}
+
 }  // namespace c8

@@ -202,6 +202,31 @@ template <class E, template <class> class ModelT> static hipError_t launch_param
   return hipGetLastError();
 }
 
+// K2 for hex8: eight elements per wavefront, 32 per workgroup (residual_wave8)
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK, 2) k_residual_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+                                                          int count, int nblocks) {
+  constexpr int WPB = BLOCK / 64;
+  using Lane = ResidualWaveLane<ModelT>;
+  __shared__ ResidualWaveShared<E> shs[WPB];
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int const e0 = (lb * WPB + wib) * 8;
+  if (e0 >= count) return;
+  Lane L;
+  GpuExec<Lane> ex(lane, L);
+  residual_wave8<E, ModelT>(ex, shs[wib], mt, ms, fa, sa, e0, (count - e0 < 8) ? count - e0 : 8);
+}
+template <class E, template <class> class ModelT> static hipError_t launch_residual_wave(LaunchArgs const& a) {
+  constexpr int EPB = (BLOCK / 64) * 8;
+  if (a.count <= 0) return hipSuccess;
+  int const nblocks = (a.count + EPB - 1) / EPB;
+  int const grid = ((nblocks + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_residual_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa, a.count, nblocks);
+  return hipGetLastError();
+}
+
 // staged assembly: one wavefront per node sums the node's rows from the element-major stage
 template <class E, int MAXDEG>
 __global__ void __launch_bounds__(BLOCK) k_gather_rows(GatherArgs ga, int first, int count, int nblocks) {
@@ -352,12 +377,14 @@ template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get_adjoint() { return nullptr; }
   static LaunchFn get_adjoint_local() { return nullptr; }
   static LaunchFn get_param_gradient() { return nullptr; }
+  static LaunchFn get_residual() { return nullptr; }
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint() { return &launch_adjoint_jacobian_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint_local() { return &launch_adjoint_local_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_param_gradient() { return &launch_param_gradient_wave<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_residual() { return &launch_residual_wave<Elem<C8_HEX8>, ModelT>; }
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
@@ -368,6 +395,7 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.adjoint_local_wave = WaveKernel<E, ModelT>::get_adjoint_local();
   ks.param_gradient_wave = WaveKernel<E, ModelT>::get_param_gradient();
   ks.residual = &launch_residual<E, ModelT>;
+  ks.residual_wave = WaveKernel<E, ModelT>::get_residual();
   ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;
   ks.param_gradient = &launch_param_gradient<E, ModelT>;

@@ -26,6 +26,7 @@ struct KernelSet {
   LaunchFn forward_jacobian;   // K1, one lane group (NDOF lanes) per element
   LaunchFn forward_jacobian_wave;  // K1, one wavefront per element (hex8 only, else null)
   LaunchFn residual;           // K2
+  LaunchFn residual_wave;      // K2, eight hex8 elements per wavefront, atomic adds (hex8 only, else null)
   LaunchFn adjoint_jacobian;   // K3
   LaunchFn adjoint_jacobian_wave;  // K3, one wavefront per element (hex8 only, else null)
   LaunchFn adjoint_local;      // K4 (per-point outputs only: one launch, no colouring)

@@ -28,7 +28,7 @@ template <class Lane, int NDOF> struct CpuExec {
   void flag(int* s) { *s = 1; }
 };
 
-enum { K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 static int g_last_nchunks = 0;
 extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
@@ -135,7 +135,25 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   delete sh;
 }
 
+template <template <class> class ModelT> static void run_residual_wave(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  auto* sh = new ResidualWaveShared<E>();
+  auto* ex = new CpuExec<ResidualWaveLane<ModelT>, 64>();
+  for (int e0 = 0; e0 < c.nelems; e0 += 8) residual_wave8<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.sa, e0, std::min(8, c.nelems - e0));
+  delete ex;
+  delete sh;
+}
+
 template <class E> static int dispatch(std::string const& model, Call const& c) {
+  if (c.what == K_RESIDUAL_WAVE) {
+    if (E::TYPE != C8_HEX8) return -4;
+    if (model == "elastic") run_residual_wave<Elastic>(c);
+    else if (model == "small_J2") run_residual_wave<SmallJ2>(c);
+    else if (model == "hyper_J2") run_residual_wave<HyperJ2>(c);
+    else if (model == "small_hill") run_residual_wave<SmallHill>(c);
+    else return -2;
+    return 0;
+  }
   if (c.what == K_ADJ_LOCAL_WAVE || c.what == K_GRAD_WAVE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "elastic") run_wave_adjoint<Elastic>(c);

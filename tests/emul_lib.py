@@ -16,6 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+K_RESIDUAL_WAVE = 11
 
 
 def lib():
@@ -88,7 +89,7 @@ class Emul:
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def global_residual(self, u, p, up, pp, xip, xi, ls):
-        return self._call(K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
+        return self._call(K_RESIDUAL_WAVE if self.wave else K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def adjoint_jacobian(self, u, p, up, pp, xip, xi, g, f, ls):
         what = (K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0)

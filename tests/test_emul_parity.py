@@ -29,6 +29,14 @@ def test_residual_only(mesh, model, params, eps):
     check_residual(orc, dut, c, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_residual_only_wave_kernel(model, params, eps):
+    # eight hex8 elements per wavefront (residual_wave8); the 4 x 3 x 3 mesh ends with a partial group of 4
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.wave = True
+    check_residual(orc, dut, c, eps, TOL)
+
+
 @pytest.mark.parametrize("mesh", MESHES)
 @pytest.mark.parametrize("model,params,eps", CASES)
 def test_adjoint_chain(mesh, model, params, eps):

@@ -72,6 +72,13 @@ def test_residual_only_matches_oracle(mesh, model, params, eps):
     check_residual(orc, gpu, c, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_residual_only_wave_kernel_hex8(model, params, eps):
+    # atomic / staged modes route hex8 residual-only assembly to the eight-elements-per-wavefront kernel
+    orc, gpu, c = make_pair(factory("atomic"), "hex8", model, params)
+    check_residual(orc, gpu, c, eps, TOL)
+
+
 @pytest.mark.parametrize("scatter", ["colored", "atomic"])
 @pytest.mark.parametrize("mesh", MESHES)
 @pytest.mark.parametrize("model,params,eps", CASES)
