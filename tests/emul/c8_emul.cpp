@@ -214,3 +214,39 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   if (rc != 0) return rc;
   return status ? -1 : 0;
 }
+
+// G5: the dual-number intrinsics and 3x3 tensor helpers of c8_math.hpp, one operation at a time:
+// out = {value, derivative} of op(a, b) with da, db the tangents of the arguments
+extern "C" int c8emu_dual_op(int op, double a, double da, double b, double db, double* out) {
+  Dual const A(a, da), B(b, db);
+  Dual r(0.);
+  switch (op) {
+    case 0: r = A + B; break;
+    case 1: r = A - B; break;
+    case 2: r = A * B; break;
+    case 3: r = A / B; break;
+    case 4: r = c8_sqrt(A); break;
+    case 5: r = c8_cbrt(A); break;
+    case 6: r = c8_exp(A); break;
+    case 7: r = c8_pow(A, B); break;
+    case 8: r = b / A; break;         // double / Dual
+    case 9: r = A / b; break;         // Dual / double
+    case 10: {                          // det and norm of a 3x3 tensor whose entries all move with the same tangent
+      Tens3<Dual> t;
+      t.xx = A; t.xy = A * 0.5; t.xz = B; t.yx = B * 2.; t.yy = A + 1.; t.yz = A - B; t.zx = B; t.zy = A * B; t.zz = A + 2.;
+      r = det(t) + norm(t);
+      break;
+    }
+    case 11: {                          // trace of inverse
+      Tens3<Dual> t;
+      t.xx = A + 3.; t.xy = B; t.xz = A * 0.1; t.yx = B * 0.2; t.yy = A + 4.; t.yz = B; t.zx = A * 0.3; t.zy = B * 0.1; t.zz = A + 5.;
+      r = trace(inverse(t));
+      break;
+    }
+    default: return -1;
+  }
+  out[0] = r.v;
+  out[1] = r.d;
+  return 0;
+}
+
