@@ -441,3 +441,22 @@ def test_full_size_million_tets_properties():
         asm.apply_A(la, t.view(-1).contiguous(), zp, yu, yp)
         scale = float(la.A[0][0].abs().max())
         assert float(yu.abs().max()) < 1e-10 * scale and float(yp.abs().max()) < 1e-10 * scale
+
+
+def test_baseline_config2_bar_100k_matches_oracle():
+    # BASELINE.json configs[1] (SURVEY.md 8d "Config 2"): 20 x 20 x 250 hex8 bar, h = 0.05, small_J2 with the
+    # parameters of notch2D_small_J2_adjoint_check.yaml.in:27-33, prescribed ramped state: the whole 100k-element
+    # assembly against the oracle (one element slice per host thread and colour)
+    from gpu_backend import GpuBackend
+    c, conn, sets = brick(20, 20, 250, 1.0, 1.0, 12.5)
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+    gpu = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="atomic")
+    u, p = prescribed_fields(c, 0.004, ramp=True)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    lo, lg, xo, xg = orc.new_linsys(), gpu.new_linsys(), orc.new_state(), gpu.new_state()
+    assert orc.forward_jacobian(u, p, z, zp, orc.new_state(), xo, lo, nthreads=min(16, os.cpu_count() or 1)) == 0
+    assert gpu.forward_jacobian(u, p, z, zp, gpu.new_state(), xg, lg) == 0
+    errs = compare_systems(orc, lg, lo)
+    errs["xi"] = rel_vec(xg, xo)
+    assert max(errs.values()) < TOL, errs
+    assert 0.2 < (xo[:, :, 6] > 0).mean() < 0.99  # elastic and plastic points both present

@@ -263,3 +263,15 @@ def test_device_inverse_problem_recovers_parameters():
     found, info = inv.solve(start, max_iters=40, grad_tol=1e-14, step_tol=1e-12, max_ls_evals=8)
     assert info["f"] < 1e-8 * J_start, (info, J_start)
     assert np.abs(found / truth[active] - 1.0).max() < 1e-3, (found, info)
+
+
+def test_baseline_config1_hex8_elastic_bar_on_device():
+    # BASELINE.json configs[0]: the 10^3 hex8 elastic bar, solved with the device Newton driver
+    from calibr8_amd import Assembler, PrimalDriver
+    c, conn, sets = brick(10, 10, 10)
+    zero = lambda x, y, z, t: 0.0
+    spec = [(0, k, sets[s], zero) for k, s in enumerate(["xmin", "ymin", "zmin"])]
+    asm = Assembler(8, c, conn, "elastic", [1000.0, 0.25, 1e-3, 10.0])
+    pr = PrimalDriver(asm, spec, max_iters=5, abs_tol=1e-10, rel_tol=1e-10).solve(1)
+    assert abs(pr.qoi() / 5.0e-3 - 1.0) < 1e-9
+    assert np.abs(pr.u[1].cpu().numpy().reshape(-1, 3) - 0.01 * c).max() < 1e-11

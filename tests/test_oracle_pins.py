@@ -77,3 +77,16 @@ def test_cube_hyperelasticity_traction(cube):
     tbcs = [Tbc(0, cube["side_sets"]["ymax"], lambda x, y, z, t: (0.0, 0.1 * t, 0.0))]
     pr = Primal(be, cube["coords"], dbcs, tbcs, max_iters=10).solve(4)
     assert rel(pr.qoi(), 1.61757374785081228e-04) < 1.0e-4
+
+
+def test_baseline_config1_hex8_elastic_bar():
+    # BASELINE.json configs[0] (SURVEY.md 8d "Config 1 (plumbing)"): 10 x 10 x 10 hex8 unit bar, `elastic` with the
+    # material of cube_elastic.yaml.in:21-27, symmetric BCs on xmin/ymin/zmin: free thermal expansion,
+    # eps = cte * dT = 0.01, so the average-displacement QoI is the deck's pin 5e-3 (times the unit volume)
+    from meshes import brick
+    c, conn, sets = brick(10, 10, 10)
+    be = ol.Oracle(ol.HEX8, c, conn, "elastic", [1000.0, 0.25, 1e-3, 10.0])
+    dbcs = [Dbc(0, k, sets[s], lambda x, y, z, t: 0.0) for k, s in enumerate(["xmin", "ymin", "zmin"])]
+    pr = Primal(be, c, dbcs).solve(1)
+    assert rel(pr.qoi(), 5.0e-3) < 1e-10
+    assert np.abs(pr.u[1].reshape(-1, 3) - 0.01 * c).max() < 1e-12  # u = eps * x exactly
