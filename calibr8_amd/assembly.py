@@ -261,6 +261,22 @@ class Assembler:
         d.reaction_comp, d.dt_over_total_time = int(comp), float(dt_over_T)
         _l.check(self.L.c8_set_qoi_calibration(self.h, C.byref(d)))
 
+    def set_allreduce(self, dist, num_parts):
+        """Multi-part objective sums: `dist` = an initialised torch.distributed module (SUM all-reduce of host doubles)."""
+        import torch
+
+        def cb(_user, vals, n):
+            t = torch.from_numpy(np.ctypeslib.as_array(vals, shape=(n,)))
+            if dist.get_backend() == "nccl":
+                d = t.to(self.device)
+                dist.all_reduce(d, op=dist.ReduceOp.SUM)
+                t.copy_(d.cpu())
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+        self._allreduce_cb = _l.ALLREDUCE_FN(cb)  # keep the callback alive
+        _l.check(self.L.c8_set_allreduce(self.h, self._allreduce_cb, None, int(num_parts)))
+
     def set_measured(self, u_meas, load_meas):
         """measured nodal displacements of the step (device tensor, kept by reference) and measured load"""
         self._u_meas = u_meas

@@ -52,6 +52,10 @@ struct c8_ctx {
   int cal_nfaces = 0, cal_nf = 0, cal_comp = 0;
   double cal_area = 0., cal_w[3] = {1., 1., 1.}, cal_balance = 0., cal_dt_over_T = 1.;
   double cal_load_meas = 0., cal_total_load = 0., cal_load_mismatch = 0.;
+  double cal_area_local = 0.;       // this part's share of the side-set area
+  c8_allreduce_fn allreduce = nullptr;  // SUM over the parts (null: one part)
+  void* allreduce_user = nullptr;
+  int num_parts = 1;
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
   int kernel_variant = C8_KERNEL_AUTO;

@@ -155,14 +155,18 @@ int c8_qoi_prepare(c8_ctx* c, FieldArgs const& fa) {
   double total = 0.;
   QH(hipMemcpyAsync(&total, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   QH(hipStreamSynchronize(c->stream));
-  c->cal_total_load = total;
-  c->cal_load_mismatch = total - c->cal_load_meas;
+  double sums[2] = {c->cal_area_local, total};
+  if (c->allreduce) c->allreduce(c->allreduce_user, sums, 2);  // PCU_Add_Double (calibration.cpp:138, :351)
+  c->cal_area = sums[0];
+  c->cal_total_load = sums[1];
+  c->cal_load_mismatch = sums[1] - c->cal_load_meas;
   return C8_OK;
 }
 
 // the face term: J (nullable) += value, b0 (nullable) -= d value / d u
 int c8_qoi_surface(c8_ctx* c, double const* u, double* J, double* b0) {
   if (c->qoi_kind == 0 || c->cal_nfaces == 0) return C8_OK;
+  if (!(c->cal_area > 0.)) return c8_fail(C8_ERR_ARG, "calibration objective: the displacement side set has no area");
   double const scale = (double)c->npts0 * c->cal_dt_over_T / c->cal_area;
   int const n = c->cal_nfaces;
   hipLaunchKernelGGL(k_surface_mismatch, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, c->cal_nf, c->d_cal_faces,
@@ -174,7 +178,8 @@ int c8_qoi_surface(c8_ctx* c, double const* u, double* J, double* b0) {
 // Calibration::postprocess on one rank: J += 1/2 balance dt/T load_mismatch^2
 int c8_qoi_postprocess(c8_ctx* c, double* J) {
   if (c->qoi_kind == 0) return C8_OK;
-  double const Jf = 0.5 * c->cal_balance * c->cal_dt_over_T * c->cal_load_mismatch * c->cal_load_mismatch;
+  // every part adds the load term; the caller's sum over the parts counts it once (J /= PCU_Comm_Peers(), :378)
+  double const Jf = 0.5 * c->cal_balance * c->cal_dt_over_T * c->cal_load_mismatch * c->cal_load_mismatch / c->num_parts;
   hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, c->stream, J, Jf);
   QH(hipGetLastError());
   return C8_OK;
@@ -226,7 +231,7 @@ int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
     for (int n = 0; n < nn; ++n)
       if (std::abs(c->mesh.coords[(size_t)en[n] * 3 + d->coord_idx] - d->coord_value) < d->coord_tol) mask[e] |= 1u << n;
   }
-  if (d->num_faces > 0 && !(area > 0.)) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
+  if (d->num_faces > 0 && !(area > 0.) && !c->allreduce) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
   std::vector<double> S;
   if (nn == 4) load_plane_sums<Elem<C8_TET4>>(c->mesh, mask, S);
   else load_plane_sums<Elem<C8_HEX8>>(c->mesh, mask, S);
@@ -242,7 +247,7 @@ int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
   QH(hipMemcpy(c->d_cal_S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
   c->cal_nfaces = (int)(faces.size() / 4);
   c->cal_nf = nfn;
-  c->cal_area = area;
+  c->cal_area = c->cal_area_local = area;  // summed over the parts at the next preprocess
   for (int k = 0; k < 3; ++k) c->cal_w[k] = d->weights[k];
   c->cal_balance = d->balance_factor;
   c->cal_comp = d->reaction_comp;
@@ -250,6 +255,14 @@ int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
   c->cal_load_meas = c->cal_total_load = c->cal_load_mismatch = 0.;
   c->d_u_meas = nullptr;
   c->qoi_kind = 1;
+  return C8_OK;
+}
+
+int c8_set_allreduce(c8_ctx* c, c8_allreduce_fn fn, void* user, int num_parts) {
+  if (!c || num_parts < 1 || (num_parts > 1 && !fn)) return c8_fail(C8_ERR_ARG, "c8_set_allreduce: bad argument");
+  c->allreduce = fn;
+  c->allreduce_user = user;
+  c->num_parts = num_parts;
   return C8_OK;
 }
 

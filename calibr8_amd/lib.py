@@ -66,6 +66,7 @@ class LbfgsResult(C.Structure):
                 ("projected_gradient_norm", C.c_double)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
@@ -100,6 +101,7 @@ SYMBOLS = [
     ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_status", C.c_int, [C.c_void_p]),
     ("c8_lbfgs_minimize", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), OBJECTIVE_FN, C.c_void_p, C.POINTER(LbfgsOpts), C.POINTER(LbfgsResult)]),
+    ("c8_set_allreduce", C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]),
     ("c8_set_qoi_avg_disp", C.c_int, [C.c_void_p]),
     ("c8_set_qoi_calibration", C.c_int, [C.c_void_p, C.POINTER(CalibrationDesc)]),
     ("c8_set_measured", C.c_int, [C.c_void_p, C.c_void_p, C.c_double]),

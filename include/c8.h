@@ -144,6 +144,12 @@ typedef struct {
   int32_t reaction_comp;              /* "reaction force component" */
   double dt_over_total_time;          /* m_dt / m_total_time */
 } c8_calibration_desc;
+/* Multi-part meshes: the calibration objective sums the side-set area and the reaction load over all parts
+ * (PCU_Add_Double, calibration.cpp:138, :351) and shares the load term of J between the parts (:375-378).  The
+ * caller supplies the SUM all-reduce over its communicator (HOST doubles, in place) and the number of parts; the
+ * library calls it from c8_qoi_preprocess and from the entry points that run preprocess_qoi. */
+typedef void (*c8_allreduce_fn)(void* user, double* values, int n);
+int c8_set_allreduce(c8_ctx* ctx, c8_allreduce_fn fn, void* user, int num_parts);
 int c8_set_qoi_avg_disp(c8_ctx* ctx);
 int c8_set_qoi_calibration(c8_ctx* ctx, const c8_calibration_desc* desc);
 /* measured data of the current step: nodal displacements (DEVICE array [nodes][3], kept by reference) and load */
