@@ -899,61 +899,86 @@ C8_HD void adjoint_local_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, Me
   });
 }
 
-// K5: eval_qoi_gradient (evaluations.cpp:758-925); lane (point, d) carries d/d(param active[d])
-template <class E, template <class> class ModelT, class QoI, class EX>
-C8_HD void param_gradient_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, ModelSettings const& ms,
-                               FieldArgs const& fa, AdjointArgs const& aa, int e) {
-  using Model = ModelT<Dual>;
-  constexpr int NL = Model::NLOC;
-  constexpr bool PREV = Model::FINITE_DEF;
-  static_assert(E::NDOF == 32 && E::NP0 == 8 && E::SAME_POINTS, "wave kernel needs a hex8-like element");
-  wave_prologue<E, NL, PREV>(ex, sh, mt, fa, aa, e);
-  int const es = mt.elem_set ? mt.elem_set[e] : 0;
-  int32_t const* act = aa.active + es * 10;
-  ex.each([&](int lane) {
-    auto& r = ex.lane(lane);
-    int const pt = lane >> 3, d = lane & 7;
-    size_t const qp = (size_t)e * E::NP0 + pt;
-    int const nact = act[1];
-    int const mine = (d < nact) ? act[2 + d] : -1;
-    int const slot = (d < nact) ? act[0] + d : -1;
-    if (slot != r.slot) {  // the group moved to another element set: flush the previous sum
-      if (r.slot >= 0) ex.add(aa.out + r.slot, r.acc, 1);
-      r.acc = 0.;
-      r.slot = slot;
+// geometry and interpolation at point pt of element slot el of an eight-element group: stores (dx/dxi)^-1 and w dv,
+// fills the point state (values only).  ZG, when not null, receives the interpolated adjoint quantities in the layout of
+// the point quantities q: grad z_u (0..8), z_p (9), grad z_p (10..12).
+template <class E, bool PREV, class SH>
+C8_HD void group_point_state(SH& sh, int el, int pt, PointState<double>& gq, double* ZG) {
+  double xi[3], w;
+  E::point(0, pt, xi, w);
+  double J[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};           // J(a,b) = dx_b / dxi_a
+  double Gu[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};          // du_i / dxi_a
+  double Gup[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  double Gz[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+  double Gp[3] = {0., 0., 0.}, pv = 0., uv[3] = {0., 0., 0.}, Gzp[3] = {0., 0., 0.}, zpv = 0.;
+  C8_UNROLL
+  for (int n = 0; n < E::NN; ++n) {
+    double g[3];
+    E::dNdxi(n, xi, g);
+    double const Nn = E::N(n, xi), pn = sh.p[el][n];
+    pv += pn * Nn;
+    if (ZG) zpv += sh.z[el][n][3] * Nn;
+    C8_UNROLL
+    for (int a = 0; a < 3; ++a) {
+      Gp[a] += pn * g[a];
+      if (ZG) Gzp[a] += sh.z[el][n][3] * g[a];
+      C8_UNROLL
+      for (int b = 0; b < 3; ++b) {
+        J[a][b] += g[a] * sh.X[el][n][b];
+        Gu[b][a] += sh.u[el][n][b] * g[a];
+        if (PREV) Gup[b][a] += sh.u_prev[el][n][b] * g[a];
+        if (ZG) Gz[b][a] += sh.z[el][n][b] * g[a];
+      }
     }
-    if (slot < 0) return;
     C8_UNROLL
-    for (int q = 0; q < Model::NPARAMS; ++q)
-      r.m.params[q] = Dual(mt.params[es * Model::NPARAMS + q], (q == mine) ? 1. : 0.);
-    load_point(sh, pt, r.g, PREV);
+    for (int b = 0; b < 3; ++b) uv[b] += sh.u[el][n][b] * Nn;
+  }
+  Tens3<double> Jt;
+  Jt.xx = J[0][0]; Jt.xy = J[0][1]; Jt.xz = J[0][2];
+  Jt.yx = J[1][0]; Jt.yy = J[1][1]; Jt.yz = J[1][2];
+  Jt.zx = J[2][0]; Jt.zy = J[2][1]; Jt.zz = J[2][2];
+  double const dJ = det(Jt);
+  Tens3<double> const Ji = inverse(Jt);
+  double const ji[9] = {Ji.xx, Ji.xy, Ji.xz, Ji.yx, Ji.yy, Ji.yz, Ji.zx, Ji.zy, Ji.zz};
+  C8_UNROLL
+  for (int q = 0; q < 9; ++q) sh.Ji[el][pt][q] = ji[q];
+  sh.wdv[el][pt] = w * dJ;
+  // d/dx_l = sum_a Ji[3l+a] d/dxi_a
+  auto phys = [&](double const* gx, int l) { return ji[3 * l] * gx[0] + ji[3 * l + 1] * gx[1] + ji[3 * l + 2] * gx[2]; };
+  gq.grad_u.xx = phys(Gu[0], 0); gq.grad_u.xy = phys(Gu[0], 1); gq.grad_u.xz = phys(Gu[0], 2);
+  gq.grad_u.yx = phys(Gu[1], 0); gq.grad_u.yy = phys(Gu[1], 1); gq.grad_u.yz = phys(Gu[1], 2);
+  gq.grad_u.zx = phys(Gu[2], 0); gq.grad_u.zy = phys(Gu[2], 1); gq.grad_u.zz = phys(Gu[2], 2);
+  if (PREV) {
+    gq.grad_u_prev.xx = phys(Gup[0], 0); gq.grad_u_prev.xy = phys(Gup[0], 1); gq.grad_u_prev.xz = phys(Gup[0], 2);
+    gq.grad_u_prev.yx = phys(Gup[1], 0); gq.grad_u_prev.yy = phys(Gup[1], 1); gq.grad_u_prev.yz = phys(Gup[1], 2);
+    gq.grad_u_prev.zx = phys(Gup[2], 0); gq.grad_u_prev.zy = phys(Gup[2], 1); gq.grad_u_prev.zz = phys(Gup[2], 2);
+  } else {
+    gq.grad_u_prev = scale(0., eye3<double>());
+  }
+  gq.p = pv;
+  C8_UNROLL
+  for (int l = 0; l < 3; ++l) { gq.grad_p[l] = phys(Gp, l); gq.u[l] = uv[l]; }
+  if (ZG) {
     C8_UNROLL
-    for (int j = 0; j < NL; ++j) {
-      r.m.xi_prev[j] = Dual(sh.xip[pt][j]);
-      r.m.xi[j] = Dual(sh.xi[pt][j]);
-      r.m.R[j] = Dual(0.);
-    }
-    r.m.evaluate(r.g, ms.abs_tol);
-    double s = 0.;
+    for (int i = 0; i < 3; ++i)
+      C8_UNROLL
+      for (int l = 0; l < 3; ++l) ZG[3 * i + l] = phys(Gz[i], l);
+    ZG[9] = zpv;
     C8_UNROLL
-    for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];   // (dC/dp)^T phi
-    s += QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, qp).d;                 // dJ/dp
-    MechFlux<Dual> f;
-    Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
-    f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);                    // both ip sets (same points)
-    s += flux_dot_zq(sh, pt, f);                                         // (dR/dp)^T z
-    r.acc += s;
-  });
-  ex.sync();
+    for (int l = 0; l < 3; ++l) ZG[10 + l] = phys(Gzp, l);
+  }
 }
-
-template <class EX> C8_HD void param_gradient_wave_flush(EX& ex, AdjointArgs const& aa) {
-  ex.each([&](int lane) {
-    auto& r = ex.lane(lane);
-    if (r.slot >= 0) ex.add(aa.out + r.slot, r.acc, 1);
-    r.slot = -1;
-    r.acc = 0.;
-  });
+// mean-square edge length of element slot el (mechanics.cpp:103-113)
+template <class E, class SH> C8_HD double group_elem_size(SH const& sh, int el) {
+  double hh = 0.;
+  C8_UNROLL
+  for (int ed = 0; ed < E::NEDGES; ++ed) {
+    int a, b;
+    E::edge(ed, a, b);
+    double const dx = sh.X[el][b][0] - sh.X[el][a][0], dy = sh.X[el][b][1] - sh.X[el][a][1], dz = sh.X[el][b][2] - sh.X[el][a][2];
+    hh += dx * dx + dy * dy + dz * dz;
+  }
+  return sqrt(hh / E::NEDGES);
 }
 
 // =====================================================================================
@@ -966,6 +991,7 @@ template <class EX> C8_HD void param_gradient_wave_flush(EX& ex, AdjointArgs con
 template <class E> struct ResidualWaveShared {
   static constexpr int NE = 8;  // elements per wavefront
   double X[NE][E::NN][3], u[NE][E::NN][3], p[NE][E::NN], u_prev[NE][E::NN][3];
+  double z[1][1][4];              // (adjoint nodal values: used by the gradient kernel's layout only)
   double Ji[NE][E::NP0][9];       // (dx/dxi)^-1, row-major: dN/dx_l = sum_a Ji[3l+a] dN/dxi_a
   double wdv[NE][E::NP0];
   double F[NE][E::NP0][WF + 1];   // point fluxes, both ip sets fused (same points on hex8)
@@ -1005,67 +1031,8 @@ C8_HD void residual_wave8(EX& ex, ResidualWaveShared<E>& sh, MeshTables const& m
     if (el >= count) return;
     auto& r = ex.lane(lane);
     int const e = e0 + el;
-    double xi[3], w;
-    E::point(0, pt, xi, w);
-    double J[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};           // J(a,b) = dx_b / dxi_a
-    double Gu[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};          // du_i / dxi_a
-    double Gup[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
-    double Gp[3] = {0., 0., 0.}, pv = 0., uv[3] = {0., 0., 0.};
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) {
-      double g[3];
-      E::dNdxi(n, xi, g);
-      double const Nn = E::N(n, xi), pn = sh.p[el][n];
-      pv += pn * Nn;
-      C8_UNROLL
-      for (int a = 0; a < 3; ++a) {
-        Gp[a] += pn * g[a];
-        C8_UNROLL
-        for (int b = 0; b < 3; ++b) {
-          J[a][b] += g[a] * sh.X[el][n][b];
-          Gu[b][a] += sh.u[el][n][b] * g[a];
-          if (PREV) Gup[b][a] += sh.u_prev[el][n][b] * g[a];
-        }
-      }
-      C8_UNROLL
-      for (int b = 0; b < 3; ++b) uv[b] += sh.u[el][n][b] * Nn;
-    }
-    Tens3<double> Jt;
-    Jt.xx = J[0][0]; Jt.xy = J[0][1]; Jt.xz = J[0][2];
-    Jt.yx = J[1][0]; Jt.yy = J[1][1]; Jt.yz = J[1][2];
-    Jt.zx = J[2][0]; Jt.zy = J[2][1]; Jt.zz = J[2][2];
-    double const dJ = det(Jt);
-    Tens3<double> const Ji = inverse(Jt);
-    double const ji[9] = {Ji.xx, Ji.xy, Ji.xz, Ji.yx, Ji.yy, Ji.yz, Ji.zx, Ji.zy, Ji.zz};
-    C8_UNROLL
-    for (int q = 0; q < 9; ++q) sh.Ji[el][pt][q] = ji[q];
-    sh.wdv[el][pt] = w * dJ;
-    // d/dx_l = sum_a Ji[3l+a] d/dxi_a
-    auto phys = [&](double const* gx, int l) { return ji[3 * l] * gx[0] + ji[3 * l + 1] * gx[1] + ji[3 * l + 2] * gx[2]; };
-    r.g.grad_u.xx = phys(Gu[0], 0); r.g.grad_u.xy = phys(Gu[0], 1); r.g.grad_u.xz = phys(Gu[0], 2);
-    r.g.grad_u.yx = phys(Gu[1], 0); r.g.grad_u.yy = phys(Gu[1], 1); r.g.grad_u.yz = phys(Gu[1], 2);
-    r.g.grad_u.zx = phys(Gu[2], 0); r.g.grad_u.zy = phys(Gu[2], 1); r.g.grad_u.zz = phys(Gu[2], 2);
-    if (PREV) {
-      r.g.grad_u_prev.xx = phys(Gup[0], 0); r.g.grad_u_prev.xy = phys(Gup[0], 1); r.g.grad_u_prev.xz = phys(Gup[0], 2);
-      r.g.grad_u_prev.yx = phys(Gup[1], 0); r.g.grad_u_prev.yy = phys(Gup[1], 1); r.g.grad_u_prev.yz = phys(Gup[1], 2);
-      r.g.grad_u_prev.zx = phys(Gup[2], 0); r.g.grad_u_prev.zy = phys(Gup[2], 1); r.g.grad_u_prev.zz = phys(Gup[2], 2);
-    } else {
-      r.g.grad_u_prev = scale(0., eye3<double>());
-    }
-    r.g.p = pv;
-    C8_UNROLL
-    for (int l = 0; l < 3; ++l) { r.g.grad_p[l] = phys(Gp, l); r.g.u[l] = uv[l]; }
-    if (pt == 0) {  // mean-square edge length, mechanics.cpp:103-113
-      double hh = 0.;
-      C8_UNROLL
-      for (int ed = 0; ed < E::NEDGES; ++ed) {
-        int a, b;
-        E::edge(ed, a, b);
-        double const dx = sh.X[el][b][0] - sh.X[el][a][0], dy = sh.X[el][b][1] - sh.X[el][a][1], dz = sh.X[el][b][2] - sh.X[el][a][2];
-        hh += dx * dx + dy * dy + dz * dz;
-      }
-      sh.h[el] = sqrt(hh / E::NEDGES);
-    }
+    group_point_state<E, PREV>(sh, el, pt, r.g, nullptr);
+    if (pt == 0) sh.h[el] = group_elem_size<E>(sh, el);
     int const es = mt.elem_set ? mt.elem_set[e] : 0;
     C8_UNROLL
     for (int q = 0; q < Model::NPARAMS; ++q) r.m.params[q] = mt.params[es * Model::NPARAMS + q];
@@ -1113,6 +1080,157 @@ C8_HD void residual_wave8(EX& ex, ResidualWaveShared<E>& sh, MeshTables const& m
     C8_UNROLL
     for (int i = 0; i < 3; ++i) ex.add(sa.b[0] + (size_t)node * 3 + i, R[i], 1);
     ex.add(sa.b[1] + node, R[3], 1);
+  });
+  ex.sync();
+}
+
+// =====================================================================================
+// K5 for hex8, eight elements per wavefront: eval_qoi_gradient (evaluations.cpp:758-925).  Lane (element, point)
+// walks the active parameters of its element set one after the other (one dual-number evaluation each):
+// (dC/dp)^T phi + dJ/dp + (dR/dp)^T z at its point.  The one-element-per-wavefront kernel (param_gradient_wave) uses
+// 8 lanes per point, of which only the active parameters (4 in the reference decks) work.
+// =====================================================================================
+template <class E> struct GradWaveShared {
+  static constexpr int NE = 8;
+  double X[NE][E::NN][3], u[NE][E::NN][3], p[NE][E::NN], u_prev[NE][E::NN][3];
+  double z[NE][E::NN][4];
+  double Ji[NE][E::NP0][9];
+  double wdv[NE][E::NP0];
+  double h[NE];
+  double red[64];
+};
+template <template <class> class ModelT> struct GradWaveLane {
+  ModelT<Dual> m;
+  PointState<Dual> g;
+  double acc[8];   // per active-parameter slot of this lane's element set
+  int slot0;       // first gradient entry of that set (-1: none yet)
+};
+
+template <class EX> C8_HD void param_gradient_wave8_flush(EX& ex, double* red, AdjointArgs const& aa) {
+  // one set in the whole wavefront (the usual case): sum over the lanes, one add per parameter; else per lane
+  // lanes that have not met an element yet (slot0 < 0) hold zeros and do not count as another set
+  int const s0 = ex.first_lane([&](int lane) { return ex.lane(lane).slot0; });
+  bool const mixed = ex.any_wave([&](int lane) { int const q = ex.lane(lane).slot0; return q >= 0 && q != s0; }) || s0 < 0;
+  static_for<8>([&](auto ac) {  // static index into acc
+    constexpr int a = decltype(ac)::value;
+    if (mixed) {
+      ex.each([&](int lane) {
+        auto& r = ex.lane(lane);
+        if (r.slot0 >= 0 && r.acc[a] != 0.) ex.add(aa.out + r.slot0 + a, r.acc[a], 1);
+      });
+    } else {
+      ex.each([&](int lane) { red[lane] = ex.lane(lane).acc[a]; });
+      ex.sync();
+      ex.each([&](int lane) {
+        if (lane == 0) {
+          double t = 0.;
+          for (int k = 0; k < 64; ++k) t += red[k];
+          if (t != 0.) ex.add(aa.out + s0 + a, t, 1);
+        }
+      });
+      ex.sync();
+    }
+  });
+  ex.each([&](int lane) {
+    auto& r = ex.lane(lane);
+    r.slot0 = -1;
+    C8_UNROLL
+    for (int a = 0; a < 8; ++a) r.acc[a] = 0.;
+  });
+}
+
+template <class E, template <class> class ModelT, class QoI, class EX>
+C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const& mt, ModelSettings const& ms,
+                                FieldArgs const& fa, AdjointArgs const& aa, int e0, int count) {
+  using Model = ModelT<Dual>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  static_assert(E::NN == 8 && E::NP0 == 8 && E::SAME_POINTS, "eight nodes, eight points, one point set");
+  ex.each([&](int lane) {
+    int const el = lane >> 3, n = lane & 7;
+    if (el >= count) return;
+    int const node = mt.conn[(size_t)(e0 + el) * E::NN + n];
+    C8_UNROLL
+    for (int d = 0; d < 3; ++d) {
+      sh.X[el][n][d] = mt.coords[(size_t)node * 3 + d];
+      sh.u[el][n][d] = fa.u[(size_t)node * 3 + d];
+      if (PREV) sh.u_prev[el][n][d] = fa.u_prev[(size_t)node * 3 + d];
+      sh.z[el][n][d] = aa.z_u[(size_t)node * 3 + d];
+    }
+    sh.p[el][n] = fa.p[node];
+    sh.z[el][n][3] = aa.z_p[node];
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    if (el >= count || pt != 0) return;
+    sh.h[el] = group_elem_size<E>(sh, el);
+  });
+  ex.sync();
+  // a lane whose element belongs to another set than its previous element's: the sums so far go out first
+  bool const moved = ex.any_wave([&](int lane) {
+    int const el = lane >> 3;
+    if (el >= count) return false;
+    int const es = mt.elem_set ? mt.elem_set[e0 + el] : 0;
+    int const s = ex.lane(lane).slot0;
+    return s >= 0 && s != aa.active[es * 10];
+  });
+  if (moved) param_gradient_wave8_flush(ex, sh.red, aa);
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    if (el >= count) return;
+    auto& r = ex.lane(lane);
+    int const e = e0 + el;
+    int const es = mt.elem_set ? mt.elem_set[e] : 0;
+    int32_t const* act = aa.active + es * 10;
+    int const nact = act[1];
+    r.slot0 = act[0];
+    PointState<double> gq;
+    double ZG[13];
+    group_point_state<E, PREV>(sh, el, pt, gq, ZG);
+    double const wdv = sh.wdv[el][pt];
+    size_t const qp = (size_t)e * E::NP0 + pt;
+    // point state as dual numbers without tangents
+    r.g.grad_u.xx = Dual(gq.grad_u.xx); r.g.grad_u.xy = Dual(gq.grad_u.xy); r.g.grad_u.xz = Dual(gq.grad_u.xz);
+    r.g.grad_u.yx = Dual(gq.grad_u.yx); r.g.grad_u.yy = Dual(gq.grad_u.yy); r.g.grad_u.yz = Dual(gq.grad_u.yz);
+    r.g.grad_u.zx = Dual(gq.grad_u.zx); r.g.grad_u.zy = Dual(gq.grad_u.zy); r.g.grad_u.zz = Dual(gq.grad_u.zz);
+    r.g.grad_u_prev.xx = Dual(gq.grad_u_prev.xx); r.g.grad_u_prev.xy = Dual(gq.grad_u_prev.xy); r.g.grad_u_prev.xz = Dual(gq.grad_u_prev.xz);
+    r.g.grad_u_prev.yx = Dual(gq.grad_u_prev.yx); r.g.grad_u_prev.yy = Dual(gq.grad_u_prev.yy); r.g.grad_u_prev.yz = Dual(gq.grad_u_prev.yz);
+    r.g.grad_u_prev.zx = Dual(gq.grad_u_prev.zx); r.g.grad_u_prev.zy = Dual(gq.grad_u_prev.zy); r.g.grad_u_prev.zz = Dual(gq.grad_u_prev.zz);
+    r.g.p = Dual(gq.p);
+    C8_UNROLL
+    for (int l = 0; l < 3; ++l) { r.g.grad_p[l] = Dual(gq.grad_p[l]); r.g.u[l] = Dual(gq.u[l]); }
+    C8_NOUNROLL
+    for (int a = 0; a < nact; ++a) {
+      int const mine = act[2 + a];
+      C8_UNROLL
+      for (int q = 0; q < Model::NPARAMS; ++q)
+        r.m.params[q] = Dual(mt.params[es * Model::NPARAMS + q], (q == mine) ? 1. : 0.);
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) {
+        r.m.xi_prev[j] = Dual(fa.xi_prev[qp * NL + j]);
+        r.m.xi[j] = Dual(fa.xi[qp * NL + j]);
+        r.m.R[j] = Dual(0.);
+      }
+      r.m.evaluate(r.g, ms.abs_tol);
+      double s = 0.;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];      // (dC/dp)^T phi (:864-866)
+      s += QoI::evaluate(r.g, r.m, wdv, aa.qoi, qp).d;                       // dJ/dp (:869-871)
+      MechFlux<Dual> f;
+      Mechanics::flux_coupled(r.m, r.g, sh.h[el], ms.stab_mult, f);
+      f.Vp = f.Vp + Mechanics::flux_pressure(r.m, r.g);                      // both ip sets (same points)
+      double t = f.Vp.d * ZG[9] + f.Gp[0].d * ZG[10] + f.Gp[1].d * ZG[11] + f.Gp[2].d * ZG[12];
+      t += f.Gu.xx.d * ZG[0] + f.Gu.xy.d * ZG[1] + f.Gu.xz.d * ZG[2];
+      t += f.Gu.yx.d * ZG[3] + f.Gu.yy.d * ZG[4] + f.Gu.yz.d * ZG[5];
+      t += f.Gu.zx.d * ZG[6] + f.Gu.zy.d * ZG[7] + f.Gu.zz.d * ZG[8];
+      s += t * wdv;                                                          // (dR/dp)^T z (:883-886)
+      // branch-free with static indices: a conditional update makes the compiler index acc dynamically (scratch)
+      static_for<8>([&](auto ac) {
+        constexpr int k = decltype(ac)::value;
+        r.acc[k] += (k == a) ? s : 0.;
+      });
+    }
   });
   ex.sync();
 }

@@ -20,6 +20,8 @@ template <class Lane> struct GpuExec {
   __device__ __forceinline__ Lane& lane(int) { return L; }
   template <class F> __device__ __forceinline__ bool any(F f) { return f(k); }
   template <class F> __device__ __forceinline__ bool any_wave(F f) { return __any(f(k)) != 0; }
+  // the value of f at the first active lane, in every lane
+  template <class F> __device__ __forceinline__ int first_lane(F f) { return __builtin_amdgcn_readfirstlane(f(k)); }
   // Lanes of one wavefront exchange data through LDS.  LDS instructions of a wave execute in order, so
   // only the compiler has to be kept from moving LDS accesses across the exchange point: a
   // wavefront-scope fence does that without draining the memory counters (a workgroup-scope fence
@@ -172,16 +174,18 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k
 template <class E, template <class> class ModelT>
 __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k_param_gradient_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
   constexpr int WPB = BLOCK / 64;
-  using Lane = WaveLaneA<ModelT>;
-  __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];
+  using Lane = GradWaveLane<ModelT>;
+  __shared__ GradWaveShared<E> shs[WPB];
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   Lane L;
-  L.slot = -1;
-  L.acc = 0.;
+  L.slot0 = -1;
+  C8_UNROLL
+  for (int a = 0; a < 8; ++a) L.acc[a] = 0.;
   GpuExec<Lane> ex(lane, L);
-  for (int e = blockIdx.x * WPB + wib; e < count; e += gridDim.x * WPB)
-    param_gradient_wave<E, ModelT, PointQoi>(ex, shs[wib], mt, ms, fa, aa, e);
-  param_gradient_wave_flush(ex, aa);
+  int const ngroups = (count + 7) / 8;
+  for (int gidx = blockIdx.x * WPB + wib; gidx < ngroups; gidx += gridDim.x * WPB)
+    param_gradient_wave8<E, ModelT, PointQoi>(ex, shs[wib], mt, ms, fa, aa, gidx * 8, (count - gidx * 8 < 8) ? count - gidx * 8 : 8);
+  param_gradient_wave8_flush(ex, shs[wib].red, aa);
 }
 
 template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local_wave(LaunchArgs const& a) {
@@ -195,9 +199,10 @@ template <class E, template <class> class ModelT> static hipError_t launch_adjoi
 }
 template <class E, template <class> class ModelT> static hipError_t launch_param_gradient_wave(LaunchArgs const& a) {
   constexpr int WPB = BLOCK / 64;
-  int const nblocks = (a.count + WPB - 1) / WPB;
   if (a.count <= 0) return hipSuccess;
-  int const grid = nblocks < 4096 ? nblocks : 4096;
+  int const ngroups = (a.count + 7) / 8;
+  int const nblocks = (ngroups + WPB - 1) / WPB;
+  int const grid = nblocks < 2048 ? nblocks : 2048;
   hipLaunchKernelGGL((k_param_gradient_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.count);
   return hipGetLastError();
 }

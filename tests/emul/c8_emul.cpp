@@ -23,6 +23,7 @@ template <class Lane, int NDOF> struct CpuExec {
   Lane& lane(int k) { return lanes[k]; }
   template <class F> bool any(F f) { bool a = false; for (int k = 0; k < NDOF; ++k) a = a || f(k); return a; }
   template <class F> bool any_wave(F f) { return any(f); }
+  template <class F> int first_lane(F f) { return f(0); }
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
   void flag(int* s) { *s = 1; }
@@ -109,14 +110,21 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
 
 template <template <class> class ModelT> static void run_wave_adjoint(Call const& c) {
   using E = Elem<C8_HEX8>;
-  auto* sh = new WaveSharedA<E, ModelT<Dual>::NLOC>();
-  auto* ex = new CpuExec<WaveLaneA<ModelT>, 64>();
-  for (int k = 0; k < 64; ++k) { ex->lanes[k].slot = -1; ex->lanes[k].acc = 0.; }
-  for (int e = 0; e < c.nelems; ++e) {
-    if (c.what == K_ADJ_LOCAL_WAVE) adjoint_local_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
-    else param_gradient_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e);
+  if (c.what == K_ADJ_LOCAL_WAVE) {
+    auto* sh = new WaveSharedA<E, ModelT<Dual>::NLOC>();
+    auto* ex = new CpuExec<WaveLaneA<ModelT>, 64>();
+    for (int e = 0; e < c.nelems; ++e) adjoint_local_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, c.sa, e);
+    delete ex;
+    delete sh;
+    return;
   }
-  if (c.what == K_GRAD_WAVE) param_gradient_wave_flush(*ex, c.aa);
+  // K5: one "wavefront" walks all groups of eight elements, as one wave of the grid-stride kernel does
+  auto* sh = new GradWaveShared<E>();
+  auto* ex = new CpuExec<GradWaveLane<ModelT>, 64>();
+  for (int k = 0; k < 64; ++k) { ex->lanes[k].slot0 = -1; for (int a = 0; a < 8; ++a) ex->lanes[k].acc[a] = 0.; }
+  for (int e0 = 0; e0 < c.nelems; e0 += 8)
+    param_gradient_wave8<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e0, std::min(8, c.nelems - e0));
+  param_gradient_wave8_flush(*ex, sh->red, c.aa);
   delete ex;
   delete sh;
 }
