@@ -7,6 +7,7 @@
 // fallback: nothing under calibr8_amd/ can reach this file.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,11 +20,16 @@ using namespace c8;
 
 template <class Lane, int NDOF> struct CpuExec {
   Lane lanes[NDOF];
-  template <class F> void each(F f) { for (int k = 0; k < NDOF; ++k) f(k); }
-  Lane& lane(int k) { return lanes[k]; }
-  template <class F> bool any(F f) { bool a = false; for (int k = 0; k < NDOF; ++k) a = a || f(k); return a; }
+  // inside each(), a lane may only touch its own registers: the GPU executor's lane(k) ignores k
+  int cur = -1;
+  template <class F> void each(F f) { for (int k = 0; k < NDOF; ++k) { cur = k; f(k); } cur = -1; }
+  Lane& lane(int k) {
+    if (cur >= 0 && k != cur) { std::fprintf(stderr, "c8emu: lane %d touched the registers of lane %d\n", cur, k); std::abort(); }
+    return lanes[k];
+  }
+  template <class F> bool any(F f) { bool a = false; for (int k = 0; k < NDOF; ++k) { cur = k; a = f(k) || a; } cur = -1; return a; }
   template <class F> bool any_wave(F f) { return any(f); }
-  template <class F> int first_lane(F f) { return f(0); }
+  template <class F> int first_lane(F f) { cur = 0; int const v = f(0); cur = -1; return v; }
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
   void flag(int* s) { *s = 1; }
