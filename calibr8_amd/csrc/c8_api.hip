@@ -413,7 +413,7 @@ int c8_eval_qoi(c8_ctx* c, const c8_state* st, double* J) {
   FieldArgs fa{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
   if (c->qoi_kind == 0) {
     AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, J, c->d_active, c8_qoi_args(c)};
-    return run(c, c->ks.qoi, fa, aa, SystemArgs{}, false, "c8_eval_qoi");
+    return run(c, c->kernel_variant == C8_KERNEL_SLOT ? c->ks.qoi_slot : c->ks.qoi, fa, aa, SystemArgs{}, false, "c8_eval_qoi");
   }
   // calibration (Calibration<double>::evaluate + postprocess): preprocess_qoi (evaluations.cpp:674), the face
   // term, and 1/2 balance dt/T load_mismatch^2

@@ -1235,4 +1235,64 @@ C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const&
   ex.sync();
 }
 
+// =====================================================================================
+// K6 for hex8, eight elements per wavefront: eval_qoi (evaluations.cpp:662-756) and the load sum of preprocess_qoi
+// (:262-347): lane (element, point) evaluates the objective integrand once; one add per wavefront at the end.
+// =====================================================================================
+template <template <class> class ModelT> struct QoiWaveLane {
+  ModelT<double> m;
+  PointState<double> g;
+  double acc;
+};
+
+template <class E, template <class> class ModelT, class QoI, class EX>
+C8_HD void qoi_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const& mt, FieldArgs const& fa, QoiArgs const& qa, int e0, int count) {
+  using Model = ModelT<double>;
+  constexpr int NL = Model::NLOC;
+  constexpr bool PREV = Model::FINITE_DEF;
+  ex.each([&](int lane) {
+    int const el = lane >> 3, n = lane & 7;
+    if (el >= count) return;
+    int const node = mt.conn[(size_t)(e0 + el) * E::NN + n];
+    C8_UNROLL
+    for (int d = 0; d < 3; ++d) {
+      sh.X[el][n][d] = mt.coords[(size_t)node * 3 + d];
+      sh.u[el][n][d] = fa.u[(size_t)node * 3 + d];
+      if (PREV) sh.u_prev[el][n][d] = fa.u_prev ? fa.u_prev[(size_t)node * 3 + d] : 0.;
+    }
+    sh.p[el][n] = fa.p[node];
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    if (el >= count) return;
+    auto& r = ex.lane(lane);
+    int const e = e0 + el;
+    group_point_state<E, PREV>(sh, el, pt, r.g, nullptr);
+    int const es = mt.elem_set ? mt.elem_set[e] : 0;
+    C8_UNROLL
+    for (int q = 0; q < Model::NPARAMS; ++q) r.m.params[q] = mt.params[es * Model::NPARAMS + q];
+    size_t const qp = (size_t)e * E::NP0 + pt;
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) {
+      r.m.xi[j] = fa.xi ? fa.xi[qp * NL + j] : 0.;
+      r.m.xi_prev[j] = fa.xi_prev ? fa.xi_prev[qp * NL + j] : 0.;
+    }
+    r.acc += QoI::evaluate(r.g, r.m, sh.wdv[el][pt], qa, qp);
+  });
+  ex.sync();
+}
+template <class EX> C8_HD void qoi_wave8_flush(EX& ex, double* red, double* out) {
+  ex.each([&](int lane) { red[lane] = ex.lane(lane).acc; ex.lane(lane).acc = 0.; });
+  ex.sync();
+  ex.each([&](int lane) {
+    if (lane == 0) {
+      double t = 0.;
+      for (int k = 0; k < 64; ++k) t += red[k];
+      ex.add(out, t, 1);
+    }
+  });
+  ex.sync();
+}
+
 }  // namespace c8

@@ -333,6 +333,31 @@ __global__ void __launch_bounds__(BLOCK) k_qoi(MeshTables mt, FieldArgs fa, Adjo
   qoi_flush<E>(ex, aa.out);
 }
 
+// K6 for hex8: eight elements per wavefront (qoi_wave8), grid-stride, one add per wavefront
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK, 2) k_qoi_wave(MeshTables mt, FieldArgs fa, AdjointArgs aa, int count) {
+  constexpr int WPB = BLOCK / 64;
+  using Lane = QoiWaveLane<ModelT>;
+  __shared__ GradWaveShared<E> shs[WPB];
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Lane L;
+  L.acc = 0.;
+  GpuExec<Lane> ex(lane, L);
+  int const ngroups = (count + 7) / 8;
+  for (int gidx = blockIdx.x * WPB + wib; gidx < ngroups; gidx += gridDim.x * WPB)
+    qoi_wave8<E, ModelT, PointQoi>(ex, shs[wib], mt, fa, aa.qoi, gidx * 8, (count - gidx * 8 < 8) ? count - gidx * 8 : 8);
+  qoi_wave8_flush(ex, shs[wib].red, aa.out);
+}
+template <class E, template <class> class ModelT> static hipError_t launch_qoi_wave(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  if (a.count <= 0) return hipSuccess;
+  int const ngroups = (a.count + 7) / 8;
+  int const nblocks = (ngroups + WPB - 1) / WPB;
+  int const grid = nblocks < 2048 ? nblocks : 2048;
+  hipLaunchKernelGGL((k_qoi_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.fa, a.aa, a.count);
+  return hipGetLastError();
+}
+
 template <class E> static void grid_for(LaunchArgs const& a, int& nblocks, int& grid) {
   constexpr int GPB = BLOCK / E::NDOF;
   nblocks = (a.count + GPB - 1) / GPB;
@@ -383,6 +408,7 @@ template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get_adjoint_local() { return nullptr; }
   static LaunchFn get_param_gradient() { return nullptr; }
   static LaunchFn get_residual() { return nullptr; }
+  static LaunchFn get_qoi() { return nullptr; }
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
@@ -390,6 +416,7 @@ template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT
   static LaunchFn get_adjoint_local() { return &launch_adjoint_local_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_param_gradient() { return &launch_param_gradient_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_residual() { return &launch_residual_wave<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_qoi() { return &launch_qoi_wave<Elem<C8_HEX8>, ModelT>; }
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
@@ -404,7 +431,8 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;
   ks.param_gradient = &launch_param_gradient<E, ModelT>;
-  ks.qoi = &launch_qoi<E, ModelT>;
+  ks.qoi = WaveKernel<E, ModelT>::get_qoi() ? WaveKernel<E, ModelT>::get_qoi() : &launch_qoi<E, ModelT>;
+  ks.qoi_slot = &launch_qoi<E, ModelT>;
   ks.gather_rows = &launch_gather_rows<E>;
   ks.stage_stride = stage_stride<E>();
   ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements

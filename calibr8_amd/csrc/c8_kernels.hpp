@@ -33,7 +33,8 @@ struct KernelSet {
   LaunchFn param_gradient;     // K5 (grid-stride, one atomic per lane at the end)
   LaunchFn adjoint_local_wave;     // K4, one wavefront per element (hex8 only, else null)
   LaunchFn param_gradient_wave;    // K5, one wavefront per element (hex8 only, else null)
-  LaunchFn qoi;                // K6
+  LaunchFn qoi;                // K6 (hex8: eight elements per wavefront)
+  LaunchFn qoi_slot;           // K6, one lane per point of a lane group (any element type)
   GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage
   int stage_stride;            // doubles per element in the stage
   bool adjoint_slot_stages;    // the slot-per-lane K3 can store into the stage (it transposes through LDS first)

@@ -35,7 +35,7 @@ template <class Lane, int NDOF> struct CpuExec {
   void flag(int* s) { *s = 1; }
 };
 
-enum { K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 static int g_last_nchunks = 0;
 extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
@@ -158,7 +158,27 @@ template <template <class> class ModelT> static void run_residual_wave(Call cons
   delete sh;
 }
 
+template <template <class> class ModelT> static void run_qoi_wave(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  auto* sh = new GradWaveShared<E>();
+  auto* ex = new CpuExec<QoiWaveLane<ModelT>, 64>();
+  for (int k = 0; k < 64; ++k) ex->lanes[k].acc = 0.;
+  for (int e0 = 0; e0 < c.nelems; e0 += 8) qoi_wave8<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.fa, c.aa.qoi, e0, std::min(8, c.nelems - e0));
+  qoi_wave8_flush(*ex, sh->red, c.aa.out);
+  delete ex;
+  delete sh;
+}
+
 template <class E> static int dispatch(std::string const& model, Call const& c) {
+  if (c.what == K_QOI_WAVE) {
+    if (E::TYPE != C8_HEX8) return -4;
+    if (model == "elastic") run_qoi_wave<Elastic>(c);
+    else if (model == "small_J2") run_qoi_wave<SmallJ2>(c);
+    else if (model == "hyper_J2") run_qoi_wave<HyperJ2>(c);
+    else if (model == "small_hill") run_qoi_wave<SmallHill>(c);
+    else return -2;
+    return 0;
+  }
   if (c.what == K_RESIDUAL_WAVE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "elastic") run_residual_wave<Elastic>(c);

@@ -16,7 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-K_RESIDUAL_WAVE = 11
+K_RESIDUAL_WAVE, K_QOI_WAVE = 11, 12
 
 
 def lib():
@@ -107,5 +107,5 @@ class Emul:
     def eval_qoi(self, u, p):
         J = np.zeros(1)
         xi = self.new_state()
-        self._call(K_QOI, {**self._fields(u, p, u, p, xi, xi), 17: J})
+        self._call(K_QOI_WAVE if self.wave else K_QOI, {**self._fields(u, p, u, p, xi, xi), 17: J})
         return float(J[0])
