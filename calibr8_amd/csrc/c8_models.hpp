@@ -338,10 +338,14 @@ struct Mechanics {
       Tens3<T> const C = cofactor(F);
       T const detF = det(F);
       stress = matmul(stress, C);  // PK1 = sigma cof(F)  (:133)
-      Tens3<T> const S = scale(tau / detF, matmul(transpose(C), C));  // :198-202
-      f.Gp[0] = -(S.xx * g.grad_p[0] + S.xy * g.grad_p[1] + S.xz * g.grad_p[2]);
-      f.Gp[1] = -(S.yx * g.grad_p[0] + S.yy * g.grad_p[1] + S.yz * g.grad_p[2]);
-      f.Gp[2] = -(S.zx * g.grad_p[0] + S.zy * g.grad_p[1] + S.zz * g.grad_p[2]);
+      // (tau / det F) C^T C grad p (:198-202), as two matrix-vector products instead of forming C^T C
+      T const v0 = C.xx * g.grad_p[0] + C.xy * g.grad_p[1] + C.xz * g.grad_p[2];
+      T const v1 = C.yx * g.grad_p[0] + C.yy * g.grad_p[1] + C.yz * g.grad_p[2];
+      T const v2 = C.zx * g.grad_p[0] + C.zy * g.grad_p[1] + C.zz * g.grad_p[2];
+      T const tj = tau / detF;
+      f.Gp[0] = -(tj * (C.xx * v0 + C.yx * v1 + C.zx * v2));
+      f.Gp[1] = -(tj * (C.xy * v0 + C.yy * v1 + C.zy * v2));
+      f.Gp[2] = -(tj * (C.xz * v0 + C.yz * v1 + C.zz * v2));
     } else {
       f.Gp[0] = -(tau * g.grad_p[0]);
       f.Gp[1] = -(tau * g.grad_p[1]);
