@@ -41,6 +41,7 @@ static int model_id(char const* name, int* nloc, int* nparams) {
   if (s == "elastic") { *nloc = Elastic<double>::NLOC; *nparams = Elastic<double>::NPARAMS; return MODEL_ELASTIC; }
   if (s == "small_J2") { *nloc = SmallJ2<double>::NLOC; *nparams = SmallJ2<double>::NPARAMS; return MODEL_SMALL_J2; }
   if (s == "hyper_J2") { *nloc = HyperJ2<double>::NLOC; *nparams = HyperJ2<double>::NPARAMS; return MODEL_HYPER_J2; }
+  if (s == "isotropic_elastic") { *nloc = IsotropicElastic<double>::NLOC; *nparams = IsotropicElastic<double>::NPARAMS; return MODEL_ISOTROPIC_ELASTIC; }
   if (s == "small_hill") { *nloc = SmallHill<double>::NLOC; *nparams = SmallHill<double>::NPARAMS; return MODEL_SMALL_HILL; }
   return MODEL_NONE;
 }
@@ -156,9 +157,14 @@ int c8_init_variables(const c8_ctx* c, double* xi) {
   size_t const npt = (size_t)c->mesh.nelems * c->npts0;
   for (size_t q = 0; q < npt; ++q) {
     double* x = xi + q * c->nloc;
-    if (c->model == MODEL_ELASTIC) Elastic<double>::init_variables(x);
-    else if (c->model == MODEL_SMALL_J2) SmallJ2<double>::init_variables(x);
-    else HyperJ2<double>::init_variables(x);
+    switch (c->model) {  // init_variables_impl of each model
+      case MODEL_ELASTIC: Elastic<double>::init_variables(x); break;
+      case MODEL_SMALL_J2: SmallJ2<double>::init_variables(x); break;
+      case MODEL_HYPER_J2: HyperJ2<double>::init_variables(x); break;
+      case MODEL_SMALL_HILL: SmallHill<double>::init_variables(x); break;
+      case MODEL_ISOTROPIC_ELASTIC: IsotropicElastic<double>::init_variables(x); break;
+      default: return fail(C8_ERR_UNSUPPORTED, "c8_init_variables: unknown model");
+    }
   }
   return C8_OK;
 }

@@ -446,6 +446,7 @@ template <class E> static KernelSet kernel_set_for(int model) {
     case MODEL_SMALL_J2: return kernel_set<E, SmallJ2>();
     case MODEL_HYPER_J2: return kernel_set<E, HyperJ2>();
     case MODEL_SMALL_HILL: return kernel_set<E, SmallHill>();
+    case MODEL_ISOTROPIC_ELASTIC: return kernel_set<E, IsotropicElastic>();
   }
   return KernelSet{};
 }

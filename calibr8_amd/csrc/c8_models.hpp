@@ -86,6 +86,53 @@ template <class T> struct Elastic {
   C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
 };
 
+// ---- isotropic_elastic.cpp (mixed formulation): the local unknown is the Cauchy stress ---------------------
+template <class T> C8_HD T compute_lambda(T const& E, T const& nu) { return E * nu / ((1. + nu) * (1. - 2. * nu)); }  // material_params.hpp:28
+template <class T> struct IsotropicElastic {
+  static constexpr int NLOC = 6, NPARAMS = 2;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
+  T params[NPARAMS];  // E nu  (isotropic_elastic.cpp:61-76)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // cauchy(00,01,02,11,12,22)
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD Tens3<T> hooke(PointState<T> const& g) const {  // lambda tr(eps) I + 2 mu eps
+    T const mu = compute_mu(params[0], params[1]), lambda = compute_lambda(params[0], params[1]);
+    Tens3<T> const eps = small_strain(g.grad_u);
+    Tens3<T> s = scale(2. * mu, eps);
+    T const lt = lambda * trace(eps);
+    s.xx = s.xx + lt; s.yy = s.yy + lt; s.zz = s.zz + lt;
+    return s;
+  }
+  // the reference starts from the exact stress and takes one Newton step (:99-121); from that start the residual
+  // vanishes, so the generic Newton loop stops at its first test with the same state
+  C8_HD void initial_guess(PointState<T> const& g) {
+    T sv[6];
+    pack_sym6(hooke(g), sv);
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(sv[k]));
+  }
+  C8_HD int evaluate(PointState<T> const& g, double, bool = false, int = 0) {  // :128-152
+    pack_sym6(sym6(xi) - hooke(g), R);
+    return 0;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const&) const { return (xi[0] + xi[3] + xi[5]) / 3.; }  // :170-181, 3-D
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :162-168
+    Tens3<T> s = sym6(xi);
+    T const h = hydro_cauchy(g);
+    s.xx = s.xx - h; s.yy = s.yy - h; s.zz = s.zz - h;
+    return s;
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // cauchy_mixed :191-197
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+};
+
 // ---- small_J2.cpp -------------------------------------------------------------
 template <class T> struct SmallJ2 {
   static constexpr int NLOC = 7, NPARAMS = 6;

@@ -866,6 +866,43 @@ template <class T> struct SmallJ2 : Local<T> {
   T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
 };
 
+// isotropic_elastic.cpp, mixed formulation (cauchy SYM_TENSOR; params E nu)
+template <class T> static T compute_lambda(T const& E, T const& nu) { return E * nu / ((1. + nu) * (1. - 2. * nu)); }  // material_params.hpp:28
+template <class T> struct IsotropicElastic : Local<T> {
+  IsotropicElastic() { this->nres = 1; this->neq[0] = 6; this->finish_layout(); }
+  int num_params() const override { return 2; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 6; ++k) xi_pt[k] = 0.; }
+  bool is_finite_deformation() const override { return false; }
+  Tens<T> hooke(Global<T>& g) {
+    T const mu = compute_mu(this->params[0], this->params[1]);
+    T const lambda = compute_lambda(this->params[0], this->params[1]);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    return (lambda * trace(eps)) * eye<T>() + (2. * mu) * eps;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // :93-122: exact initial guess, then exactly one Newton step
+    if (std::is_same<T, double>::value) return 0;
+    this->set_sym_tensor_xi_val(0, hooke(g));
+    int const path = this->evaluate(g, false, 0);
+    double J[64], r[8], dxi[8];
+    this->jacobian(this->ndofs, J);
+    this->residual_values(r);
+    for (int k = 0; k < this->ndofs; ++k) r[k] = -r[k];
+    full_piv_lu_solve(this->ndofs, 1, J, r, dxi);
+    this->add_to_xi(dxi);
+    return path;
+  }
+  int evaluate(Global<T>& g, bool, int) override {  // :128-152
+    Tens<T> const R_cauchy = this->sym_tensor_xi(0) - hooke(g);
+    this->set_sym_tensor_R(0, R_cauchy);
+    return 0;
+  }
+  T hydro_cauchy(Global<T>&) override { return trace(this->sym_tensor_xi(0)) / 3.; }  // :170-181
+  Tens<T> dev_cauchy(Global<T>& g) override { return this->sym_tensor_xi(0) - this->hydro_cauchy(g) * eye<T>(); }  // :162-168
+  Tens<T> cauchy(Global<T>& g) override { return this->dev_cauchy(g) - g.scalar_x(1) * eye<T>(); }  // :191-197
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
 // small_hill.cpp (pstrain SYM_TENSOR, alpha SCALAR; params E nu Y R00 R11 R22 R01 R02 R12 S D);
 // Hill's yield function and its normal: yield_functions.hpp:34-99
 template <class T> struct SmallHill : Local<T> {
@@ -1120,6 +1157,7 @@ template <class T> Local<T>* make_local(std::string const& type) {  // local_res
   if (type == "small_J2") return new SmallJ2<T>();
   if (type == "hyper_J2") return new HyperJ2<T>();
   if (type == "small_hill") return new SmallHill<T>();
+  if (type == "isotropic_elastic") return new IsotropicElastic<T>();
   return nullptr;
 }
 

@@ -176,6 +176,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_J2") run_qoi_wave<SmallJ2>(c);
     else if (model == "hyper_J2") run_qoi_wave<HyperJ2>(c);
     else if (model == "small_hill") run_qoi_wave<SmallHill>(c);
+    else if (model == "isotropic_elastic") run_qoi_wave<IsotropicElastic>(c);
     else return -2;
     return 0;
   }
@@ -185,6 +186,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_J2") run_residual_wave<SmallJ2>(c);
     else if (model == "hyper_J2") run_residual_wave<HyperJ2>(c);
     else if (model == "small_hill") run_residual_wave<SmallHill>(c);
+    else if (model == "isotropic_elastic") run_residual_wave<IsotropicElastic>(c);
     else return -2;
     return 0;
   }
@@ -194,6 +196,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_J2") run_wave_adjoint<SmallJ2>(c);
     else if (model == "hyper_J2") run_wave_adjoint<HyperJ2>(c);
     else if (model == "small_hill") run_wave_adjoint<SmallHill>(c);
+    else if (model == "isotropic_elastic") run_wave_adjoint<IsotropicElastic>(c);
     else return -2;
     return 0;
   }
@@ -203,6 +206,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_J2") run_wave<SmallJ2>(c);
     else if (model == "hyper_J2") run_wave<HyperJ2>(c);
     else if (model == "small_hill") run_wave<SmallHill>(c);
+    else if (model == "isotropic_elastic") run_wave<IsotropicElastic>(c);
     else return -2;
     return 0;
   }
@@ -210,6 +214,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
   else if (model == "small_J2") run<E, SmallJ2>(c);
   else if (model == "hyper_J2") run<E, HyperJ2>(c);
   else if (model == "small_hill") run<E, SmallHill>(c);
+  else if (model == "isotropic_elastic") run<E, IsotropicElastic>(c);
   else return -2;
   return 0;
 }

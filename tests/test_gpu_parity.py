@@ -65,6 +65,13 @@ def test_forward_jacobian_matches_oracle(mesh, model, params, eps, scatter):
     check_forward(orc, gpu, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES)
+def test_initial_local_state_matches_oracle(model, params, eps):
+    # init_variables_impl of every registered model (c8_init_variables)
+    orc, gpu, c = make_pair(factory("colored"), "hex8", model, params)
+    assert np.array_equal(gpu.new_state(), orc.new_state())
+
+
 @pytest.mark.parametrize("mesh", MESHES)
 @pytest.mark.parametrize("model,params,eps", CASES)
 def test_residual_only_matches_oracle(mesh, model, params, eps):

@@ -61,7 +61,8 @@ def test_shape_partition_of_unity_and_gradients():
 @pytest.mark.parametrize("model,params,eps", [("small_J2", J2, 0.004), ("small_J2", J2, 0.001),
                                               ("elastic", [1000.0, 0.25, 1e-3, 10.0], 0.002),
                                               ("hyper_J2", [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0], 0.004),
-                                              ("small_hill", [1000.0, 0.25, 2.0, 1.0, 1.1, 0.9, 1.05, 0.95, 1.0, 1.0, 50.0], 0.004)])
+                                              ("small_hill", [1000.0, 0.25, 2.0, 1.0, 1.1, 0.9, 1.05, 0.95, 1.0, 1.0, 50.0], 0.004),
+                                              ("isotropic_elastic", [1000.0, 0.25], 0.002)])
 def test_jacobian_matches_finite_differences_hex8(model, params, eps):
     c, conn, sets = brick(3, 2, 2, 1.0, 0.8, 0.7)
     c = jiggle(c, sets, 0.05)
@@ -220,3 +221,22 @@ def test_calibration_qoi_value_and_fd_gradient():
     errs = np.array(errs)
     assert errs.min() < 1e-6 * abs(gd), (errs, gd)
     assert np.log10(errs.max() / errs.min()) > 4.0, (errs, gd)
+
+
+def test_isotropic_elastic_equals_elastic_without_thermal_strain():
+    # two formulations of the same material: `elastic` condenses nothing, `isotropic_elastic` carries the stress as
+    # its local unknown (isotropic_elastic.cpp); residual and condensed Jacobian must coincide
+    c, conn, sets = brick(3, 2, 2, 1.0, 0.8, 0.7)
+    c = jiggle(c, sets, 0.05)
+    u, p = prescribed_fields(c, 0.002, ramp=True, perturb=5e-2)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    out = []
+    for model, params in (("elastic", [1000.0, 0.25, 0.0, 0.0]), ("isotropic_elastic", [1000.0, 0.25])):
+        be = ol.Oracle(ol.HEX8, c, conn, model, params)
+        ls, xi = be.new_linsys(), be.new_state()
+        assert be.forward_jacobian(u, p, z, zp, be.new_state(), xi, ls) == 0
+        out.append(ls)
+    for i in range(2):
+        assert np.abs(out[0].b[i] - out[1].b[i]).max() < 1e-12 * np.abs(out[0].b[i]).max()
+        for j in range(2):
+            assert np.abs(out[0].A[i][j] - out[1].A[i][j]).max() < 1e-12 * np.abs(out[0].A[i][j]).max()
