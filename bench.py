@@ -240,6 +240,36 @@ def main():
                                      ("<hex8,small_J2> into the element stage + k_gather_rows, per chunk of elements"
                                       if args.scatter == "gather" else "<hex8,small_J2> (%d launches per step)"
                                       % (asm.ncolors if args.scatter == "colored" else 1))}
+        if world == 1:
+            # beside the headline (untimed above): the other entry points of the path on the same mesh and state,
+            # HIP-event milliseconds per call (BASELINE config 2: primal + adjoint dR/dp assembly on one GPU)
+            asm.set_active(0, [0, 1, 2, 3])
+            g_h = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=dev)
+            f_h = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=dev)
+            phi = torch.zeros_like(g_h)
+            z_u, z_p = torch.randn_like(u) * 1e-3, torch.randn_like(p) * 1e-3
+            grad = torch.zeros(4, dtype=torch.float64, device=dev)
+            Jq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+            def ms_of(fn, reps=3):
+                fn()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+
+            out["other_entry_points_ms"] = {
+                "c8_assemble_adjoint_jacobian": ms_of(lambda: asm.adjoint_jacobian(u, p, u0, p0, xi_prev, xi, g_h, f_h, ls)),
+                "c8_solve_adjoint_local": ms_of(lambda: asm.solve_adjoint_local(u, p, u0, p0, xi_prev, xi, z_u, z_p, phi, g_h, f_h)),
+                "c8_param_gradient": ms_of(lambda: asm.qoi_gradient(u, p, u0, p0, xi_prev, xi, z_u, z_p, phi, grad)),
+                "c8_assemble_residual": ms_of(lambda: asm.global_residual(u, p, u0, p0, xi_prev, xi, ls)),
+                "c8_eval_qoi": ms_of(lambda: asm.eval_qoi(u, p, Jq)),
+            }
+            assert asm.status() == 0
+            del g_h, f_h, phi
         if not args.no_cpu and world == 1:
             try:
                 avail = len(os.sched_getaffinity(0))
