@@ -522,8 +522,17 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
         size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
         size_t const in_row = pos * neqb + eqb;
         size_t const urow0 = nptr * (3 * neqb);     // first u row of node n in block (0, ib)
+#ifdef C8_EXPERIMENT_BLOCKED_LAYOUT
+        // timing experiment only (results are not a CSR assembly): node-blocked values, one 4x4 block of 128
+        // contiguous bytes per node pair, written over the caller's contiguous A00|A01|A10|A11 allocation
+        double* const blk = sa.A[0][0] + (nptr + pos) * 16 + (ib == 0 ? eqb : 3);
+        ex.add(blk + (2 * g) * 4, r.J[2 * n], ATOMIC);
+        ex.add(blk + (g ? 3 : 1) * 4, r.J[2 * n + 1], ATOMIC);
+        (void)A0; (void)A1; (void)deg; (void)in_row; (void)urow0;
+#else
         ex.add(A0 + urow0 + (size_t)(2 * g) * deg * neqb + in_row, r.J[2 * n], ATOMIC);
         ex.add(A1 + (g ? nptr * neqb : urow0 + deg * neqb) + in_row, r.J[2 * n + 1], ATOMIC);
+#endif
       }
       if (g == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, ATOMIC);
     };
