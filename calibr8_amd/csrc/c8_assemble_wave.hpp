@@ -543,8 +543,8 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       double* const st = sa.stage + (size_t)(e % sa.stage_ring) * stage_stride<E>();
       C8_UNROLL
       for (int n = 0; n < E::NN; ++n) {  // two runs of 32 contiguous values per store
-        st[stage_row<E>(n, 2 * g) + b] = r.J[2 * n];            // row u_2g of node n
-        st[stage_row<E>(n, g ? 3 : 1) + b] = r.J[2 * n + 1];    // row p or u_1
+        C8_STREAM_STORE(st + stage_row<E>(n, 2 * g) + b, r.J[2 * n]);            // row u_2g of node n
+        C8_STREAM_STORE(st + stage_row<E>(n, g ? 3 : 1) + b, r.J[2 * n + 1]);    // row p or u_1
       }
       if (g == 0) st[E::NN * 4 * E::NDOF + b] = r.R;
     } else if (sa.atomic) {
@@ -631,7 +631,7 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
               int const c = idx % E::NDOF;
               int const m = c < 3 * E::NN ? c / 3 : c - 3 * E::NN;
               r.pos[k][j] = ga.pos[((size_t)e * E::NN + m) * E::NN + ln];
-              r.v[k][j] = st[stage_row<E>(ln, 0) + idx];
+              r.v[k][j] = C8_STREAM_LOAD(st + stage_row<E>(ln, 0) + idx);
             }
           }
           r.rv[k] = (lane < 4) ? st[E::NN * 4 * E::NDOF + (lane < 3 ? 3 * ln + lane : 3 * E::NN + ln)] : 0.;

@@ -22,6 +22,14 @@
 #endif
 // every small fixed-trip loop must be fully unrolled on the GPU so that register
 // arrays are only ever indexed by compile-time constants (no scratch memory)
+// stage traffic is written once and read once much later: keep it out of the caches (nontemporal on the GPU)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C8_STREAM_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#define C8_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define C8_STREAM_STORE(p, v) (*(p) = (v))
+#define C8_STREAM_LOAD(p) (*(p))
+#endif
 #if defined(__clang__)
 #define C8_UNROLL _Pragma("unroll")
 #define C8_NOUNROLL _Pragma("clang loop unroll(disable)")
