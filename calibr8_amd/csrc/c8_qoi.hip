@@ -17,6 +17,7 @@
 
 #include "../../include/c8.h"
 #include "c8_api_internal.hpp"
+#include "c8_qoi_host.hpp"
 
 using namespace c8;
 
@@ -28,64 +29,8 @@ using namespace c8;
 
 namespace {
 
-// element faces in local node ids (this library's numbering of the downward faces; the reference only uses
-// the face to find its nodes)
-int const TET_FACES[4][3] = {{0, 1, 2}, {0, 1, 3}, {1, 2, 3}, {0, 2, 3}};
-int const HEX_FACES[6][4] = {{0, 1, 2, 3}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
-
-// order-2 rule on a face (calibration.cpp:262-266): tri3 3 points, quad4 2x2 Gauss; Nf = face shape functions,
-// wdv = weight * getDV.  Returns the number of points.
-__host__ __device__ inline int face_rule(int nf, double const X[][3], double Nf[][4], double* wdv) {
-  if (nf == 3) {
-    double a[3], b[3];
-    for (int d = 0; d < 3; ++d) { a[d] = X[1][d] - X[0][d]; b[d] = X[2][d] - X[0][d]; }
-    double const c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
-    double const dv = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
-    double const st[3][2] = {{1. / 6., 1. / 6.}, {2. / 3., 1. / 6.}, {1. / 6., 2. / 3.}};
-    for (int q = 0; q < 3; ++q) {
-      Nf[q][0] = 1. - st[q][0] - st[q][1]; Nf[q][1] = st[q][0]; Nf[q][2] = st[q][1]; Nf[q][3] = 0.;
-      wdv[q] = dv / 6.;
-    }
-    return 3;
-  }
-  double const gp = 0.5773502691896257645;
-  double const sn[4] = {-1., 1., 1., -1.}, tn[4] = {-1., -1., 1., 1.};
-  int q = 0;
-  for (int j = 0; j < 2; ++j)
-    for (int i = 0; i < 2; ++i, ++q) {
-      double const s = (i ? gp : -gp), t = (j ? gp : -gp);
-      double ds[3] = {0., 0., 0.}, dt[3] = {0., 0., 0.};
-      for (int k = 0; k < 4; ++k) {
-        Nf[q][k] = 0.25 * (1. + sn[k] * s) * (1. + tn[k] * t);
-        for (int d = 0; d < 3; ++d) {
-          ds[d] += 0.25 * sn[k] * (1. + tn[k] * t) * X[k][d];
-          dt[d] += 0.25 * tn[k] * (1. + sn[k] * s) * X[k][d];
-        }
-      }
-      double const c0 = ds[1] * dt[2] - ds[2] * dt[1], c1 = ds[2] * dt[0] - ds[0] * dt[2], c2 = ds[0] * dt[1] - ds[1] * dt[0];
-      wdv[q] = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
-    }
-  return 4;
-}
-// face area by the one-point rule of calibration.cpp:122-126
-double face_area(int nf, double const X[][3]) {
-  if (nf == 3) {
-    double Nf[4][4], wdv[4];
-    face_rule(3, X, Nf, wdv);
-    return 3. * wdv[0];
-  }
-  double const sn[4] = {-1., 1., 1., -1.}, tn[4] = {-1., -1., 1., 1.};
-  double ds[3] = {0., 0., 0.}, dt[3] = {0., 0., 0.};
-  for (int k = 0; k < 4; ++k)
-    for (int d = 0; d < 3; ++d) { ds[d] += 0.25 * sn[k] * X[k][d]; dt[d] += 0.25 * tn[k] * X[k][d]; }
-  double const c0 = ds[1] * dt[2] - ds[2] * dt[1], c1 = ds[2] * dt[0] - ds[0] * dt[2], c2 = ds[0] * dt[1] - ds[1] * dt[0];
-  return 4. * std::sqrt(c0 * c0 + c1 * c1 + c2 * c2);
-}
-
-// compute_surface_mismatch (calibration.cpp:225-300), one thread per (element, face) pair of the side set.
-// At a face point the element's shape functions reduce to the face's own, so the interpolation of the element
-// field at boundaryToElementXi(point) is the face interpolation of the nodal values.  `scale` carries
-// mult * dt/T / area, mult = the number of coupled points (the reference adds the face integral at every one).
+// the face term, one thread per (element, face) pair of the side set.  `scale` carries mult * dt/T / area, mult = the
+// number of coupled points (the reference adds the face integral at every one).
 // J (if not null) += value; b0 (if not null) -= d value / d u   (the adjoint right-hand side is -dJ/dx).
 __global__ void k_surface_mismatch(int n, int nf, int32_t const* face_nodes, double const* coords, double const* u,
                                    double const* u_meas, double w0, double w1, double w2, double scale, double* J,
@@ -93,22 +38,9 @@ __global__ void k_surface_mismatch(int n, int nf, int32_t const* face_nodes, dou
   int const f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n) return;
   int32_t const* fn = face_nodes + (size_t)f * 4;
-  double X[4][3], Nf[4][4], wdv[4], du[4][3];
-  for (int k = 0; k < nf; ++k)
-    for (int d = 0; d < 3; ++d) {
-      X[k][d] = coords[(size_t)fn[k] * 3 + d];
-      du[k][d] = u[(size_t)fn[k] * 3 + d] - u_meas[(size_t)fn[k] * 3 + d];
-    }
-  int const nq = face_rule(nf, X, Nf, wdv);
   double const wt[3] = {w0, w1, w2};
-  double val = 0., grad[4][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
-  for (int q = 0; q < nq; ++q)
-    for (int d = 0; d < 3; ++d) {
-      double diff = 0.;
-      for (int k = 0; k < nf; ++k) diff += du[k][d] * Nf[q][k];
-      val += 0.5 * wt[d] * diff * diff * wdv[q];
-      for (int k = 0; k < nf; ++k) grad[k][d] += wt[d] * diff * Nf[q][k] * wdv[q];
-    }
+  double grad[4][3];
+  double const val = surface_mismatch_face(nf, fn, coords, u, u_meas, wt, grad);
   if (J) unsafeAtomicAdd(J, val * scale);
   if (b0)
     for (int k = 0; k < nf; ++k)
@@ -116,23 +48,6 @@ __global__ void k_surface_mismatch(int n, int nf, int32_t const* face_nodes, dou
 }
 
 __global__ void k_add_scalar(double* x, double v) { *x += v; }
-
-// S[e][pt][j] = sum over the element's nodes on the load plane of dN_n/dx_j at coupled point pt
-template <class E> void load_plane_sums(HostMesh const& m, std::vector<unsigned> const& mask, std::vector<double>& S) {
-  S.assign((size_t)m.nelems * E::NP0 * 3, 0.);
-  GroupShared<E, 1> sh;
-  for (int e = 0; e < m.nelems; ++e) {
-    if (!mask[e]) continue;
-    for (int n = 0; n < E::NN; ++n)
-      for (int d = 0; d < 3; ++d) sh.X[n][d] = m.coords[(size_t)m.conn[(size_t)e * E::NN + n] * 3 + d];
-    for (int pt = 0; pt < E::NP0; ++pt) {
-      shape_entry<E>(sh, 0, pt, 0, E::NN);
-      for (int n = 0; n < E::NN; ++n)
-        if (mask[e] & (1u << n))
-          for (int j = 0; j < 3; ++j) S[((size_t)e * E::NP0 + pt) * 3 + j] += sh.dN[pt][n][j];
-    }
-  }
-}
 
 }  // namespace
 
@@ -198,43 +113,12 @@ int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
   int const nn = c->mesh.nn, nfn = (nn == 4) ? 3 : 4, nfe = (nn == 4) ? 4 : 6;
   if (d->num_faces > 0 && d->nodes_per_face != nfn) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: faces must have 3 nodes (tet4) or 4 (hex8)");
   if (d->coord_idx < 0 || d->coord_idx > 2 || d->reaction_comp < 0 || d->reaction_comp > 2) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: coordinate index / component out of range");
-  std::set<std::vector<int32_t>> side;
-  for (int f = 0; f < d->num_faces; ++f) {
-    std::vector<int32_t> key(d->faces + (size_t)f * nfn, d->faces + (size_t)(f + 1) * nfn);
-    std::sort(key.begin(), key.end());
-    side.insert(key);
-  }
-  // m_mapping_disp (calibration.cpp:98-135): one face per element, a later downward face overwrites an earlier
-  // one, every match adds its area; m_mapping_load (qoi.cpp:160-198)
-  std::vector<int32_t> faces;
-  std::vector<unsigned> mask((size_t)c->mesh.nelems, 0u);
-  double area = 0.;
-  for (int e = 0; e < c->mesh.nelems; ++e) {
-    int32_t const* en = &c->mesh.conn[(size_t)e * nn];
-    int hit = -1;
-    for (int dn = 0; dn < nfe; ++dn) {
-      int const* loc = (nn == 4) ? TET_FACES[dn] : HEX_FACES[dn];
-      std::vector<int32_t> key(nfn);
-      for (int k = 0; k < nfn; ++k) key[k] = en[loc[k]];
-      std::sort(key.begin(), key.end());
-      if (!side.count(key)) continue;
-      hit = dn;
-      double X[4][3];
-      for (int k = 0; k < nfn; ++k)
-        for (int q = 0; q < 3; ++q) X[k][q] = c->mesh.coords[(size_t)en[loc[k]] * 3 + q];
-      area += face_area(nfn, X);
-    }
-    if (hit >= 0) {
-      int const* loc = (nn == 4) ? TET_FACES[hit] : HEX_FACES[hit];
-      for (int k = 0; k < 4; ++k) faces.push_back(k < nfn ? en[loc[k]] : -1);
-    }
-    for (int n = 0; n < nn; ++n)
-      if (std::abs(c->mesh.coords[(size_t)en[n] * 3 + d->coord_idx] - d->coord_value) < d->coord_tol) mask[e] |= 1u << n;
-  }
+  CalibrationTables t;
+  calibration_tables(c->mesh, d->num_faces, d->faces, d->coord_idx, d->coord_value, d->coord_tol, t);
+  std::vector<int32_t> const& faces = t.faces;
+  std::vector<double> const& S = t.S;
+  double const area = t.area;
   if (d->num_faces > 0 && !(area > 0.) && !c->allreduce) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
-  std::vector<double> S;
-  if (nn == 4) load_plane_sums<Elem<C8_TET4>>(c->mesh, mask, S);
-  else load_plane_sums<Elem<C8_HEX8>>(c->mesh, mask, S);
   (void)hipFree(c->d_cal_faces);
   (void)hipFree(c->d_cal_S);
   c->d_cal_faces = nullptr;

@@ -15,6 +15,7 @@
 #include "../../calibr8_amd/csrc/c8_assemble_adjoint.hpp"
 #include "../../calibr8_amd/csrc/c8_assemble_wave.hpp"
 #include "../../calibr8_amd/csrc/c8_host.hpp"
+#include "../../calibr8_amd/csrc/c8_qoi_host.hpp"
 
 using namespace c8;
 
@@ -35,7 +36,34 @@ template <class Lane, int NDOF> struct CpuExec {
   void flag(int* s) { *s = 1; }
 };
 
-enum { K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+
+// objective configuration for the next calls (what c8_set_qoi_calibration / c8_set_measured keep in the context)
+struct EmuQoi {
+  int kind = 0;  // 0 average displacement, 1 calibration
+  std::vector<int32_t> side_faces;
+  int nfaces = 0, coord_idx = 0, comp = 0;
+  double coord_value = 0., coord_tol = 0., w[3] = {1., 1., 1.}, balance = 0., dt_over_T = 1.;
+  std::vector<double> u_meas;
+  double load_meas = 0., load_mismatch = 0., total_load = 0., area = 0.;
+};
+static EmuQoi g_qoi;
+extern "C" void c8emu_set_qoi_avg_disp() { g_qoi = EmuQoi(); }
+extern "C" void c8emu_set_qoi_calibration(int nfaces, int npf, int const* faces, double const* weights, double balance,
+                                          int coord_idx, double coord_value, double coord_tol, int comp, double dt_over_T) {
+  g_qoi = EmuQoi();
+  g_qoi.kind = 1;
+  g_qoi.nfaces = nfaces;
+  g_qoi.side_faces.assign(faces, faces + (size_t)nfaces * npf);
+  for (int d = 0; d < 3; ++d) g_qoi.w[d] = weights[d];
+  g_qoi.balance = balance; g_qoi.coord_idx = coord_idx; g_qoi.coord_value = coord_value; g_qoi.coord_tol = coord_tol;
+  g_qoi.comp = comp; g_qoi.dt_over_T = dt_over_T;
+}
+extern "C" void c8emu_set_measured(int n, double const* u_meas, double load_meas) {
+  g_qoi.u_meas.assign(u_meas, u_meas + n);
+  g_qoi.load_meas = load_meas;
+}
+extern "C" void c8emu_qoi_info(double* out) { out[0] = g_qoi.area; out[1] = g_qoi.total_load; out[2] = g_qoi.load_mismatch; }
 
 static int g_last_nchunks = 0;
 extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
@@ -249,7 +277,57 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
   c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};
   c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active, QoiArgs{1., 0., 0, nullptr}};
-  int const rc = (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c);
+  auto run_it = [&]() { return (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c); };
+  int const base = c.what;
+  bool const is_qoi = base == K_QOI || base == K_QOI_WAVE, is_k3 = base == K_ADJ_JAC || base == K_ADJ_JAC_WAVE,
+             is_k5 = base == K_GRAD || base == K_GRAD_WAVE, is_pre = base == K_QOI_PREPROCESS;
+  if (g_qoi.kind == 1 && (is_qoi || is_k3 || is_k5 || is_pre)) {
+    // the sequence of c8_qoi.hip: tables (set-up), preprocess_qoi, then the entry point with the point integrand
+    CalibrationTables t;
+    calibration_tables(mesh, g_qoi.nfaces, g_qoi.side_faces.data(), g_qoi.coord_idx, g_qoi.coord_value, g_qoi.coord_tol, t);
+    g_qoi.area = t.area;
+    int const npts0 = (elem_type == C8_HEX8) ? Elem<C8_HEX8>::NP0 : Elem<C8_TET4>::NP0;
+    double total = 0.;
+    {
+      Call pc = c;
+      pc.what = (elem_type == C8_HEX8 && (base == K_QOI_WAVE || base == K_ADJ_JAC_WAVE || base == K_GRAD_WAVE)) ? K_QOI_WAVE : K_QOI;
+      pc.staged = 0;
+      pc.aa.out = &total;
+      pc.aa.qoi = QoiArgs{0., 1., g_qoi.comp, t.S.data()};
+      Call const saved = c;
+      c = pc;
+      int const rc0 = run_it();
+      c = saved;
+      if (rc0 != 0) return rc0;
+    }
+    g_qoi.total_load = total;
+    g_qoi.load_mismatch = total - g_qoi.load_meas;
+    if (is_pre) return 0;
+    double const scale = (double)npts0 * g_qoi.dt_over_T / t.area;
+    auto surface = [&](double* J, double* b0) {
+      for (size_t f = 0; f < t.faces.size() / 4; ++f) {
+        int32_t const* fn = &t.faces[f * 4];
+        double grad[4][3];
+        double const val = surface_mismatch_face(t.nfn, fn, mesh.coords.data(), ptrs[0], g_qoi.u_meas.data(), g_qoi.w, grad);
+        if (J) *J += val * scale;
+        if (b0)
+          for (int k = 0; k < t.nfn; ++k)
+            for (int d = 0; d < 3; ++d) b0[(size_t)fn[k] * 3 + d] -= grad[k][d] * scale;
+      }
+    };
+    if (is_qoi) {  // Calibration<double>::evaluate + postprocess
+      surface(ptrs[17], nullptr);
+      *ptrs[17] += 0.5 * g_qoi.balance * g_qoi.dt_over_T * g_qoi.load_mismatch * g_qoi.load_mismatch;
+      return 0;
+    }
+    c.aa.qoi = QoiArgs{0., g_qoi.balance * g_qoi.dt_over_T * g_qoi.load_mismatch, g_qoi.comp, t.S.data()};
+    int const rc = run_it();
+    if (rc != 0) return rc;
+    if (is_k3) surface(nullptr, ptrs[10]);
+    return status ? -1 : 0;
+  }
+  if (is_pre) return 0;
+  int const rc = run_it();
   if (rc != 0) return rc;
   return status ? -1 : 0;
 }

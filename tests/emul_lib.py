@@ -16,7 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-K_RESIDUAL_WAVE, K_QOI_WAVE = 11, 12
+K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS = 11, 12, 13
 
 
 def lib():
@@ -67,6 +67,7 @@ class Emul:
 
     def _call(self, what, ptrs):
         o = self.orc
+        self._push_objective()
         arr = (dp * 18)()
         for k, a in ptrs.items():
             arr[k] = a.ctypes.data_as(dp)
@@ -104,8 +105,48 @@ class Emul:
         self._call(K_GRAD_WAVE if self.wave else K_GRAD, {**self._fields(u, p, up, pp, xip, xi), 14: z_u, 15: z_p, 16: phi, 17: grad})
         return grad
 
+    # ---- Calibration objective (the emulator keeps one objective configuration, like a context) ----
+    def set_calibration(self, faces, weights=(1.0, 1.0, 1.0), balance=1.0, coord_idx=1, coord_value=0.0, coord_tol=1e-8,
+                        comp=1, dt_over_T=1.0):
+        self._cal = (np.ascontiguousarray(faces, dtype=np.int32), np.ascontiguousarray(weights, dtype=np.float64), balance,
+                     coord_idx, coord_value, coord_tol, comp, dt_over_T)
+        self._meas = None
+        self.calibration = True
+
+    def set_measured(self, u_meas, load_meas):
+        self._meas = (np.ascontiguousarray(u_meas, dtype=np.float64), float(load_meas))
+
+    def _push_objective(self):
+        """the library keeps ONE objective configuration: install this object's before every call"""
+        L = lib()
+        cal = getattr(self, "_cal", None)
+        if cal is None:
+            L.c8emu_set_qoi_avg_disp()
+            return
+        f, w, balance, coord_idx, coord_value, coord_tol, comp, dt_over_T = cal
+        L.c8emu_set_qoi_calibration.argtypes = [C.c_int, C.c_int, ip, dp, C.c_double, C.c_int, C.c_double, C.c_double,
+                                                C.c_int, C.c_double]
+        L.c8emu_set_qoi_calibration(f.shape[0], f.shape[1], f.ctypes.data_as(ip), w.ctypes.data_as(dp), balance, coord_idx,
+                                    coord_value, coord_tol, comp, dt_over_T)
+        if self._meas is not None:
+            L.c8emu_set_measured.argtypes = [C.c_int, dp, C.c_double]
+            L.c8emu_set_measured(len(self._meas[0]), self._meas[0].ctypes.data_as(dp), self._meas[1])
+
+    def qoi_preprocess(self, u, p, up, pp, xip, xi):
+        self._qoi_state = (u, p, up, pp, xip, xi)
+        J = np.zeros(1)
+        self._call(K_QOI_PREPROCESS | (0 if not self.wave else 0), {**self._fields(u, p, up, pp, xip, xi), 17: J})
+        out = np.zeros(3)
+        lib().c8emu_qoi_info.argtypes = [dp]
+        lib().c8emu_qoi_info(out.ctypes.data_as(dp))
+        return out
+
     def eval_qoi(self, u, p):
         J = np.zeros(1)
-        xi = self.new_state()
-        self._call(K_QOI_WAVE if self.wave else K_QOI, {**self._fields(u, p, u, p, xi, xi), 17: J})
+        st = getattr(self, "_qoi_state", None)
+        if st is None:
+            xi = self.new_state()
+            self._call(K_QOI_WAVE if self.wave else K_QOI, {**self._fields(u, p, u, p, xi, xi), 17: J})
+        else:  # calibration: the state of the step given to qoi_preprocess
+            self._call(K_QOI_WAVE if self.wave else K_QOI, {**self._fields(u, p, st[2], st[3], st[4], st[5]), 17: J})
         return float(J[0])

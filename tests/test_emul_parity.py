@@ -102,3 +102,52 @@ def test_two_element_sets(kind, wave):
 
 def test_tiny_and_ragged_meshes():
     check_tiny_and_ragged(factory, TOL)
+
+
+@pytest.mark.parametrize("kind,wave", [("hex8", True), ("hex8", False), ("tet4", False)])
+def test_calibration_objective(kind, wave):
+    # Calibration QoI (calibration.cpp) through the kernel source on the CPU: set-up tables, preprocess (total load),
+    # value, and the x / xi / parameter derivatives through K3 -> K4 -> K5, against the oracle
+    import numpy as np
+    import oracle_lib as ol
+    from parity import compare_systems, rel_vec
+    from parity_cases import J2, mesh_of, two_steps
+    et, c, conn = mesh_of(kind)
+    xmax, ymin = c[:, 0].max(), c[:, 1].min()
+    loc = ([0, 1, 2], [0, 1, 3], [1, 2, 3], [0, 2, 3]) if et == ol.TET4 else \
+        ([0, 1, 2, 3], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7], [4, 5, 6, 7])
+    faces = [[int(e[k]) for k in f] for e in conn for f in loc if all(abs(c[e[k], 0] - xmax) < 0.06 for k in f)]
+    faces = [f for f in faces if all(abs(c[n, 0] - xmax) < 0.06 for n in f)]
+    assert faces
+    kw = dict(weights=(1.0, 2.0, 0.5), balance=0.3, coord_idx=1, coord_value=float(ymin), coord_tol=0.06, comp=1, dt_over_T=0.5)
+    orc = ol.Oracle(et, c, conn, "small_J2", J2)
+    dut = factory(et, c, conn, "small_J2", J2)
+    dut.wave = wave
+    orc.set_calibration(faces, **kw)
+    dut.set_calibration(faces, **kw)
+    st = two_steps(orc, c, 0.004)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    rng = np.random.default_rng(3)
+    u_meas = u + 1e-4 * rng.standard_normal(len(u))
+    for b in (orc, dut):
+        b.set_active(0, [0, 1, 2, 3])
+        b.set_measured(u_meas, -0.7)
+    po, pd = orc.qoi_preprocess(u, p, up, pp, xip, xi), dut.qoi_preprocess(u, p, up, pp, xip, xi)
+    assert np.abs(po - pd).max() < 1e-12 * max(1.0, np.abs(po).max()), (po, pd)
+    Jo, Jd = orc.eval_qoi(u, p), dut.eval_qoi(u, p)
+    assert abs(Jo - Jd) < 1e-12 * abs(Jo), (Jo, Jd)
+    res = []
+    for b in (orc, dut):
+        g = np.full((orc.nelems, orc.npts, orc.nloc), 0.01)
+        f = np.full((orc.nelems, orc.npts, 4 * orc.nn), 0.02)
+        ls = b.new_linsys()
+        b.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, ls)
+        z_u, z_p = np.linspace(-1e-3, 1e-3, len(u)), np.linspace(2e-3, -1e-3, len(p))
+        phi = np.zeros_like(g)
+        b.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
+        res.append((ls, g, f, phi, b.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 4)))
+    (lo, go, fo, pho, gro), (ld, gd, fd, phd, grd) = res
+    errs = compare_systems(orc, ld, lo)
+    errs["g"], errs["f"], errs["phi"] = rel_vec(gd, go), rel_vec(fd, fo), rel_vec(phd, pho)
+    errs["grad"] = float(np.abs(grd - gro).max() / np.abs(gro).max())
+    assert max(errs.values()) < TOL, errs
