@@ -98,11 +98,19 @@ static hipError_t launch_forward(LaunchArgs const& a) {
   return hipGetLastError();
 }
 
-// K1, one wavefront per hex8 element (c8_assemble_wave.hpp); 4 elements per workgroup
+// One wavefront per workgroup for the wave Jacobian kernels: a workgroup's registers and LDS are released only when
+// its last wavefront retires, and element durations differ (elastic / plastic points, Newton iterations), so with four
+// wavefronts per workgroup finished slots idle until the slowest is done (12.5 ms against 12.7-12.9 ms).
+#ifndef C8_JBLOCK
+#define C8_JBLOCK 64
+#endif
+constexpr int JBLOCK = C8_JBLOCK;
+// K1, one wavefront per hex8 element (c8_assemble_wave.hpp)
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU) k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+__global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(ModelT<Dual>::WAVE_BLOCKS_PER_CU, ModelT<Dual>::WAVE_BLOCKS_PER_CU)))
+k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
                                                                int first, int count, int nblocks) {
-  constexpr int WPB = BLOCK / 64;
+  constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLane<ModelT>;
   __shared__ WaveShared<E, ModelT<Dual>::NLOC> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
@@ -118,19 +126,20 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU) k_for
 
 template <class E, template <class> class ModelT>
 static hipError_t launch_forward_wave(LaunchArgs const& a) {
-  constexpr int WPB = BLOCK / 64;
+  constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
   int const grid = ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_forward_jacobian_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
+  hipLaunchKernelGGL((k_forward_jacobian_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
                      a.first, a.count, nblocks);
   return hipGetLastError();
 }
 
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU) k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+__global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(ModelT<Dual>::WAVE_BLOCKS_PER_CU, ModelT<Dual>::WAVE_BLOCKS_PER_CU)))
+k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
                                                                   SystemArgs sa, int first, int count, int nblocks) {
-  constexpr int WPB = BLOCK / 64;
+  constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLane<ModelT>;
   __shared__ WaveShared<E, ModelT<Dual>::NLOC> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
@@ -146,19 +155,20 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU) k_adj
 
 template <class E, template <class> class ModelT>
 static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
-  constexpr int WPB = BLOCK / 64;
+  constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
   int const grid = ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_adjoint_jacobian_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa,
+  hipLaunchKernelGGL((k_adjoint_jacobian_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa,
                      a.sa, a.first, a.count, nblocks);
   return hipGetLastError();
 }
 
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
+__global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ)))
+k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
                                                                SystemArgs sa, int first, int count, int nblocks) {
-  constexpr int WPB = BLOCK / 64;
+  constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLaneA<ModelT>;
   __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
@@ -189,11 +199,11 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k
 }
 
 template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local_wave(LaunchArgs const& a) {
-  constexpr int WPB = BLOCK / 64;
+  constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
   int const grid = ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_adjoint_local_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.sa,
+  hipLaunchKernelGGL((k_adjoint_local_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.sa,
                      a.first, a.count, nblocks);
   return hipGetLastError();
 }
