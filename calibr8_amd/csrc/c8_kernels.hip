@@ -10,7 +10,10 @@
 
 namespace c8 {
 
-constexpr int BLOCK = 256;
+#ifndef C8_BLOCK
+#define C8_BLOCK 64
+#endif
+constexpr int BLOCK = C8_BLOCK;
 
 template <class Lane> struct GpuExec {
   int k;
