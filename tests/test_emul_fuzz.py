@@ -18,7 +18,7 @@ def test_random_case_emulated_kernels_match_oracle(seed):
     dut = em.Emul(et, c, conn, model, params)
     dut.wave = kind == "hex8" and kernel == "auto"
     dut.staged = scatter == "gather"
-    tol = 4e-12 if model == "hyper_J2" else 1e-12
+    tol = 1e-10 if model == "hyper_J2" else 1e-12  # see test_gpu_fuzz.py
     check_forward(orc, dut, c, model, eps, tol)
     check_residual(orc, dut, c, eps, tol)
     if not (kind == "hex8" and not dut.wave and dut.staged):
