@@ -39,7 +39,7 @@ struct c8_ctx {
   double* d_stage = nullptr;          // [ring][stage_stride], allocated at the first staged assembly
   int32_t* d_node_order = nullptr;
   c8::StagePlan plan;                 // staged assembly: chunks, ring, node order
-  int stage_min_chunk = 131072;
+  int stage_min_chunk = 0;            // 0: automatic (c8_api.hip: stage_setup)
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
   int* d_status = nullptr;

@@ -116,8 +116,9 @@ int c8_set_active_params(c8_ctx* ctx, int elem_set, int n, const int32_t* param_
 int c8_num_active_params(const c8_ctx* ctx); /* total over element sets = length of grad */
 int c8_set_stream(c8_ctx* ctx, void* hip_stream);
 int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_COLORED (default), C8_SCATTER_ATOMIC or C8_SCATTER_GATHER */
-/* C8_SCATTER_GATHER tuning: elements are staged in chunks of at least `min_chunk` elements (default 131072; the
- * chunk is never smaller than the element bandwidth of the mesh) through a ring of three chunks. */
+/* C8_SCATTER_GATHER tuning: elements are staged in chunks of at least `min_chunk` elements (the chunk is never
+ * smaller than the element bandwidth of the mesh) through a ring of three chunks.  Default: the whole mesh in one
+ * chunk while its stage stays under 12 GB (8.4 KB per hex8, 2.2 KB per tet4 element), else chunks of 262144. */
 int c8_set_stage_chunk(c8_ctx* ctx, int min_chunk);
 /* Forward-assembly kernel: C8_KERNEL_SLOT = one lane group per element (any element type);
  * C8_KERNEL_WAVE = one wavefront per element (hex8); C8_KERNEL_AUTO picks WAVE where available. */
