@@ -112,6 +112,28 @@ def test_reference_regressions_with_device_newton_driver(deck):
     assert abs(pr.qoi() / expected - 1) < tol, (pr.qoi(), pr.newton_iters)
 
 
+@pytest.mark.parametrize("deck", ["notch_small_J2", "notch_hyper_J2"])
+def test_notch_regressions_with_device_newton_driver(deck):
+    # the reference's 3-D notch decks (1550 tets read out of test/mesh/notch/notch0.smb, tests/golden/make_notch_fixture.py),
+    # four plastic load steps, every assembly, boundary condition and Newton update on the device.  `notch_small_J2`
+    # selects `small_hill` with R = 1 (notch_small_J2.yaml.in:21): the reference's 3-D small-strain plasticity regression.
+    # The CPU oracle reproduces both pins to 2e-15 (test_oracle_pins.py); the deck tolerance is 1e-4.
+    from calibr8_amd import Assembler, PrimalDriver
+    d = json.load(open(os.path.join(HERE, "golden", "notch_tet4.json")))
+    c, conn, ns = np.array(d["coords"]), np.array(d["conn"], dtype=np.int32), d["node_sets"]
+    zero = lambda x, y, z, t: 0.0
+    sym = [(0, 0, ns["xmin"], zero), (0, 1, ns["ymin"], zero), (0, 2, ns["zmin"], zero)]
+    if deck == "notch_small_J2":
+        asm = Assembler(4, c, conn, "small_hill", [1000.0, 0.25, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 10.0, 2.0], max_iters=500)
+        pr = PrimalDriver(asm, sym + [(0, 1, ns["ymax"], lambda x, y, z, t: 0.001 * t)]).solve(4)
+        expected = 1.4622046563394649e-04
+    else:
+        asm = Assembler(4, c, conn, "hyper_J2", [1000.0, 0.25, 10.0, 0.0, 0.0, 0.0, 0.0, 100.0], max_iters=500)
+        pr = PrimalDriver(asm, sym + [(0, 1, ns["ymax"], lambda x, y, z, t: 0.005 * t)]).solve(4)
+        expected = 7.0080671510235862e-04
+    assert abs(pr.qoi() / expected - 1) < 1e-9, (pr.qoi(), pr.newton_iters)
+
+
 def test_device_newton_driver_matches_oracle_driven_newton():
     # same problem, Newton history and solution: C++ driver on the GPU vs the Python driver on the oracle
     from calibr8_amd import Assembler, PrimalDriver

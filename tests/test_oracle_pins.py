@@ -1,7 +1,9 @@
 """Pin the CPU oracle against the reference's own regression values.
 
 Each case reproduces a deck under /root/reference/source/calibr8/test/primal/ on the
-shipped cube mesh (tests/golden/cube_tet4.json, generated from test/mesh/cube/cube.msh):
+shipped cube mesh (tests/golden/cube_tet4.json, generated from test/mesh/cube/cube.msh) or the
+shipped notch mesh (tests/golden/notch_tet4.json, read out of test/mesh/notch/notch0.smb by
+tests/golden/make_notch_fixture.py, whose .smb reader is checked against the cube's gmsh file):
 same material, boundary conditions, load steps and tolerances; the expected value and
 its tolerance are the deck's `regression:` block.
 """
@@ -77,6 +79,35 @@ def test_cube_hyperelasticity_traction(cube):
     tbcs = [Tbc(0, cube["side_sets"]["ymax"], lambda x, y, z, t: (0.0, 0.1 * t, 0.0))]
     pr = Primal(be, cube["coords"], dbcs, tbcs, max_iters=10).solve(4)
     assert rel(pr.qoi(), 1.61757374785081228e-04) < 1.0e-4
+
+
+@pytest.fixture(scope="module")
+def notch():
+    d = json.load(open(os.path.join(HERE, "golden", "notch_tet4.json")))
+    d["coords"] = np.array(d["coords"], dtype=np.float64)
+    d["conn"] = np.array(d["conn"], dtype=np.int32)
+    return d
+
+
+def test_notch_small_J2_deck_is_small_hill(notch):
+    # primal/notch_small_J2.yaml.in: 1550 tets, 4 steps, ymax pulled by 0.001*t; the deck selects `small_hill` (:21)
+    # with all R = 1 and Voce hardening Y 2, S 10, D 2 (:26-37); pin :50-51.  The 3-D small-strain plasticity pin.
+    be = ol.Oracle(ol.TET4, notch["coords"], notch["conn"], "small_hill",
+                   [1000.0, 0.25, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 10.0, 2.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    dbcs = sym_dbcs(notch) + [Dbc(0, 1, notch["node_sets"]["ymax"], lambda x, y, z, t: 0.001 * t)]
+    pr = Primal(be, notch["coords"], dbcs, max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 1.4622046563394649e-04) < 1.0e-11  # deck tolerance 1e-4; measured 3.7e-16
+    assert pr.xi[-1][:, :, 6].max() > 1e-4  # the notch root has yielded
+
+
+def test_notch_hyper_J2(notch):
+    # primal/notch_hyper_J2.yaml.in: 4 steps, ymax pulled by 0.005*t, Y 10, K 100 (:26-34); pin :47-48
+    be = ol.Oracle(ol.TET4, notch["coords"], notch["conn"], "hyper_J2",
+                   [1000.0, 0.25, 10.0, 0.0, 0.0, 0.0, 0.0, 100.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    dbcs = sym_dbcs(notch) + [Dbc(0, 1, notch["node_sets"]["ymax"], lambda x, y, z, t: 0.005 * t)]
+    pr = Primal(be, notch["coords"], dbcs, max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 7.0080671510235862e-04) < 1.0e-11  # deck tolerance 1e-4; measured 1.7e-15
+    assert pr.xi[-1][:, :, 7].max() > 1e-4
 
 
 def test_baseline_config1_hex8_elastic_bar():
