@@ -70,6 +70,11 @@ template <template <class> class ModelT> struct WaveLane {
   double b[Model::NLOC];
   double J[16];   // phase P: rows of this lane's half, column b
   double R;
+  // issued with the first loads of the element, used much later: the previous / current local state of this lane's
+  // (point, direction) and the eight CSR positions of this lane's column node (their round trips would otherwise
+  // be exposed after the shape tables and in front of the scatter)
+  double xi_pre, xip_pre;
+  unsigned long long pos8;
   int iter;
   double R_norm_0;
   bool converged, failed;
@@ -195,6 +200,18 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     C8_UNROLL
     for (int a = 0; a < 16; ++a) r.J[a] = 0.;
     if (lane == 0) sh.failed = 0;
+    {
+      int const pt = lane >> 3, d = lane & 7;
+      r.xi_pre = r.xip_pre = 0.;
+      if (d < NL) {
+        size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+        r.xip_pre = fa.xi_prev[q + d];
+        r.xi_pre = fa.xi[q + d];
+      }
+      int ib, nb, eqb;
+      slot_to_dof<E>(lane & 31, ib, nb, eqb);
+      r.pos8 = *reinterpret_cast<unsigned long long const*>(mt.pos + ((size_t)e * E::NN + nb) * E::NN);  // pos[e][col node nb][0..7]
+    }
     if (lane < E::NDOF) {
       int i, n, eq;
       slot_to_dof<E>(lane, i, n, eq);
@@ -228,9 +245,9 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       if (d == 0) sh.qprev[pt][8] = interp_q<E>(sh, pt, 8, true);
     }
     if (d < NL) {
-      size_t const q = ((size_t)e * E::NP0 + pt) * NL;
-      sh.xip[pt][d] = fa.xi_prev[q + d];
-      sh.xi[pt][d] = fa.xi[q + d];
+      auto& r = ex.lane(lane);
+      sh.xip[pt][d] = r.xip_pre;
+      sh.xi[pt][d] = r.xi_pre;
     }
   });
   ex.sync();
@@ -508,7 +525,6 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
     int ib, nb, eqb;
     slot_to_dof<E>(b, ib, nb, eqb);
     int const neqb = ib == 0 ? 3 : 1;
-    uint8_t const* posb = mt.pos + ((size_t)e * E::NN + nb) * E::NN;  // pos[e][col node nb][row node]
     // forward: J[(n,i)][b]; adjoint: the lane already holds the transposed entries J[b][(n,i)], so in both
     // cases this is assembled entry (row (n,i), column b) and the lanes of one instruction share 2 rows.
     // One uniform branch selects atomic or plain adds for the whole batch (a branch per add would keep the
@@ -519,7 +535,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       constexpr int ATOMIC = decltype(mode)::value;
       C8_UNROLL
       for (int n = 0; n < E::NN; ++n) {
-        size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = posb[n];
+        size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = (size_t)((r.pos8 >> (8 * n)) & 0xff);  // pos[e][nb][row node n]
         size_t const in_row = pos * neqb + eqb;
         size_t const urow0 = nptr * (3 * neqb);     // first u row of node n in block (0, ib)
 #ifdef C8_EXPERIMENT_BLOCKED_LAYOUT
@@ -730,6 +746,7 @@ template <template <class> class ModelT> struct WaveLaneA {
   double b[Model::NLOC];
   double acc;
   int slot;
+  double xi_pre, xip_pre;  // local state of this lane's (point, direction), loaded with the first loads of the element
 };
 
 // interpolate the adjoint nodal values like the point quantities (same B matrix)
@@ -764,6 +781,16 @@ template <class E, int NL, bool PREV, class EX, class SH>
 C8_HD void wave_prologue(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& fa, AdjointArgs const& aa, int e) {
   ex.each([&](int lane) {
     if (lane == 0) sh.failed = 0;
+    {
+      auto& r = ex.lane(lane);
+      int const pt = lane >> 3, d = lane & 7;
+      r.xi_pre = r.xip_pre = 0.;
+      if (d < NL) {
+        size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+        r.xip_pre = fa.xi_prev[q + d];
+        r.xi_pre = fa.xi[q + d];
+      }
+    }
     if (lane < E::NDOF) {
       int i, n, eq;
       slot_to_dof<E>(lane, i, n, eq);
@@ -797,9 +824,9 @@ C8_HD void wave_prologue(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& 
       if (d == 0) sh.qprev[pt][8] = interp_q<E>(sh, pt, 8, true);
     }
     if (d < NL) {
-      size_t const q = ((size_t)e * E::NP0 + pt) * NL;
-      sh.xip[pt][d] = fa.xi_prev[q + d];
-      sh.xi[pt][d] = fa.xi[q + d];
+      auto& r = ex.lane(lane);
+      sh.xip[pt][d] = r.xip_pre;
+      sh.xi[pt][d] = r.xi_pre;
     }
   });
   ex.sync();

@@ -167,8 +167,13 @@ static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
   return hipGetLastError();
 }
 
+#ifdef C8_EXPERIMENT_K4_WAVES  // timing experiment: waves per SIMD of the local-adjoint kernel, every model
+#define C8_K4_WAVES(M) C8_EXPERIMENT_K4_WAVES
+#else
+#define C8_K4_WAVES(M) M::WAVE_BLOCKS_PER_CU_ADJ
+#endif
 template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ)))
+__global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(C8_K4_WAVES(ModelT<Dual>), C8_K4_WAVES(ModelT<Dual>))))
 k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa,
                                                                SystemArgs sa, int first, int count, int nblocks) {
   constexpr int WPB = JBLOCK / 64;

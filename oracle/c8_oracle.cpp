@@ -997,6 +997,154 @@ template <class T> struct SmallHill : Local<T> {
   T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
 };
 
+// minitensor::polar_rotation (Trilinos MiniTensor_LinearAlgebra.t.h, third party, not under /root/reference): the
+// rotation R of F = R U by Newton's iteration X <- (mu X + X^-T / mu) / 2 with Higham's 1-norm/inf-norm scaling
+// ("Functions of Matrices", algorithm 8.20), differentiated through like any other arithmetic.  The converged R is
+// unique, so the pin below does not depend on the iteration's details.
+template <class T> T norm_1(Tens<T> const& A) {  // largest absolute column sum
+  T best = abs(A(0, 0)) + abs(A(1, 0)) + abs(A(2, 0));
+  for (int j = 1; j < 3; ++j) {
+    T const s = abs(A(0, j)) + abs(A(1, j)) + abs(A(2, j));
+    if (val(s) > val(best)) best = s;
+  }
+  return best;
+}
+template <class T> T norm_infinity(Tens<T> const& A) {  // largest absolute row sum
+  T best = abs(A(0, 0)) + abs(A(0, 1)) + abs(A(0, 2));
+  for (int i = 1; i < 3; ++i) {
+    T const s = abs(A(i, 0)) + abs(A(i, 1)) + abs(A(i, 2));
+    if (val(s) > val(best)) best = s;
+  }
+  return best;
+}
+template <class T> Tens<T> polar_rotation(Tens<T> const& A) {
+  bool scale = true;
+  double const tol_scale = 0.01;
+  double const tol_conv = std::sqrt(3.) * 2.220446049250313e-16;
+  Tens<T> X = A;
+  double gamma = 2.0;
+  for (int num_iter = 0; num_iter < 128; ++num_iter) {
+    Tens<T> const Y = inverse(X);
+    T mu = 1.0;
+    if (scale) {
+      mu = (norm_1(Y) * norm_infinity(Y)) / (norm_1(X) * norm_infinity(X));
+      mu = sqrt(sqrt(mu));
+    }
+    Tens<T> const Z = 0.5 * (mu * X + transpose(Y) / mu);
+    Tens<T> const D = Z - X;
+    double const nD = val(norm(D));
+    double const delta = nD / val(norm(Z));
+    if (scale && delta < tol_scale) scale = false;
+    bool const end_iter = nD <= std::sqrt(tol_conv) || (delta > 0.5 * gamma && !scale);
+    X = Z;
+    gamma = delta;
+    if (end_iter) break;
+  }
+  return X;
+}
+
+// hypo_hill.cpp (TC SYM_TENSOR = unrotated Cauchy stress, alpha SCALAR; params E nu Y R00 R11 R22 R01 R02 R12 S D):
+// hypoelastic rate form in the unrotated configuration, Hill yield function, Voce hardening
+template <class T> struct HypoHill : Local<T> {
+  HypoHill() { this->nres = 2; this->neq[0] = 6; this->neq[1] = 1; this->finish_layout(); }
+  int num_params() const override { return 11; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 7; ++k) xi_pt[k] = 0.; }  // :123-131
+  bool is_finite_deformation() const override { return true; }
+  Tens<T> rotation(Global<T>& g) { return polar_rotation(g.grad_vector_x(0) + eye<T>()); }  // global_residual.hpp:302-305
+  Tens<T> eval_d(Global<T>& g) {  // :134-139, hypo_kinematics.hpp:11-18
+    Tens<T> const I = eye<T>();
+    Tens<T> const F = g.grad_vector_x(0) + I;
+    Tens<T> const F_prev = g.grad_vector_x_prev(0) + I;
+    Tens<T> const R = polar_rotation(F);
+    Tens<T> const L = (F - F_prev) * inverse(F);
+    Tens<T> const D = 0.5 * (L + transpose(L));
+    return transpose(R) * D * R;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // :147-203
+    if (std::is_same<T, double>::value) return 0;
+    {
+      double const E = val(this->params[0]), nu = val(this->params[1]);
+      double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+      Tens<T> const I = eye<T>();
+      Tens<T> const TC_old = this->sym_tensor_xi_prev(0);
+      T const alpha_old = this->scalar_xi_prev(1);
+      Tens<T> const d = eval_d(g);
+      Tens<T> const TC = TC_old + (lambda * trace(d)) * I + (2. * mu) * d;
+      this->set_sym_tensor_xi_val(0, TC);
+      this->set_scalar_xi_val(1, val(alpha_old));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :211-289
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2];
+    T const R00 = this->params[3], R11 = this->params[4], R22 = this->params[5];
+    T const R01 = this->params[6], R02 = this->params[7], R12 = this->params[8];
+    T const S = this->params[9], D = this->params[10];
+    T const lambda = compute_lambda(E, nu);
+    T const mu = compute_mu(E, nu);
+    auto inv2 = [](T const& r) { return 1. / (r * r); };  // std::pow(r, -2)
+    T hp[6];  // compute_hill_params (yield_functions.hpp:35-50)
+    hp[0] = 0.5 * (inv2(R11) + inv2(R22) - inv2(R00));
+    hp[1] = 0.5 * (inv2(R22) + inv2(R00) - inv2(R11));
+    hp[2] = 0.5 * (inv2(R00) + inv2(R11) - inv2(R22));
+    hp[3] = 1.5 * inv2(R12);
+    hp[4] = 1.5 * inv2(R02);
+    hp[5] = 1.5 * inv2(R01);
+    Tens<T> const TC_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1);
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    T const d12 = TC(1, 1) - TC(2, 2), d20 = TC(2, 2) - TC(0, 0), d01 = TC(0, 0) - TC(1, 1);
+    T const hill = sqrt(hp[0] * d12 * d12 + hp[1] * d20 * d20 + hp[2] * d01 * d01 +
+                        2. * (hp[3] * TC(1, 2) * TC(1, 2) + hp[4] * TC(0, 2) * TC(0, 2) + hp[5] * TC(0, 1) * TC(0, 1)));
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    Tens<T> const I = eye<T>();
+    Tens<T> const d = eval_d(g);
+    Tens<T> R_TC = TC - TC_old - (lambda * trace(d)) * I - (2. * mu) * d;
+    R_TC = R_TC / val(mu);
+    T R_alpha;
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    if (plastic) {
+      Tens<T> n;  // compute_hill_normal (:74-99)
+      n(0, 0) = (hp[1] + hp[2]) * TC(0, 0) - hp[2] * TC(1, 1) - hp[1] * TC(2, 2);
+      n(1, 1) = (hp[0] + hp[2]) * TC(1, 1) - hp[2] * TC(0, 0) - hp[0] * TC(2, 2);
+      n(2, 2) = (hp[1] + hp[0]) * TC(2, 2) - hp[1] * TC(0, 0) - hp[0] * TC(1, 1);
+      n(0, 1) = hp[5] * TC(0, 1); n(0, 2) = hp[4] * TC(0, 2); n(1, 2) = hp[3] * TC(1, 2);
+      n(1, 0) = n(0, 1); n(2, 0) = n(0, 2); n(2, 1) = n(1, 2);
+      n = n / hill;
+      T const dgam = alpha - alpha_old;
+      R_TC = R_TC + ((2. * mu * dgam) * n) / val(mu);
+      R_alpha = f;
+    } else {
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_TC);
+    this->set_scalar_R(1, R_alpha);
+    return path;
+  }
+  Tens<T> rotated_cauchy(Global<T>& g) {  // :292-298
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    Tens<T> const R = rotation(g);
+    return R * TC * transpose(R);
+  }
+  Tens<T> cauchy(Global<T>& g) override {  // :301-310
+    T const p = g.scalar_x(1);
+    return this->dev_cauchy(g) - p * eye<T>();
+  }
+  Tens<T> dev_cauchy(Global<T>& g) override { return dev(rotated_cauchy(g)); }  // :313-316
+  T hydro_cauchy(Global<T>& g) override { return trace(rotated_cauchy(g)) / 3.; }  // :319-322
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
 // hyper_J2.cpp (zeta SYM_TENSOR, Ie SCALAR, alpha SCALAR; params E nu Y S D A n K)
 template <class T> struct HyperJ2 : Local<T> {
   HyperJ2() { this->nres = 3; this->neq[0] = 6; this->neq[1] = 1; this->neq[2] = 1; this->finish_layout(); }
@@ -1158,6 +1306,7 @@ template <class T> Local<T>* make_local(std::string const& type) {  // local_res
   if (type == "hyper_J2") return new HyperJ2<T>();
   if (type == "small_hill") return new SmallHill<T>();
   if (type == "isotropic_elastic") return new IsotropicElastic<T>();
+  if (type == "hypo_hill") return new HypoHill<T>();
   return nullptr;
 }
 
