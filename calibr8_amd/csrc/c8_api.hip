@@ -42,6 +42,7 @@ static int model_id(char const* name, int* nloc, int* nparams) {
   if (s == "small_J2") { *nloc = SmallJ2<double>::NLOC; *nparams = SmallJ2<double>::NPARAMS; return MODEL_SMALL_J2; }
   if (s == "hyper_J2") { *nloc = HyperJ2<double>::NLOC; *nparams = HyperJ2<double>::NPARAMS; return MODEL_HYPER_J2; }
   if (s == "isotropic_elastic") { *nloc = IsotropicElastic<double>::NLOC; *nparams = IsotropicElastic<double>::NPARAMS; return MODEL_ISOTROPIC_ELASTIC; }
+  if (s == "hypo_hill") { *nloc = HypoHill<double>::NLOC; *nparams = HypoHill<double>::NPARAMS; return MODEL_HYPO_HILL; }
   if (s == "small_hill") { *nloc = SmallHill<double>::NLOC; *nparams = SmallHill<double>::NPARAMS; return MODEL_SMALL_HILL; }
   return MODEL_NONE;
 }
@@ -163,6 +164,7 @@ int c8_init_variables(const c8_ctx* c, double* xi) {
       case MODEL_HYPER_J2: HyperJ2<double>::init_variables(x); break;
       case MODEL_SMALL_HILL: SmallHill<double>::init_variables(x); break;
       case MODEL_ISOTROPIC_ELASTIC: IsotropicElastic<double>::init_variables(x); break;
+      case MODEL_HYPO_HILL: HypoHill<double>::init_variables(x); break;
       default: return fail(C8_ERR_UNSUPPORTED, "c8_init_variables: unknown model");
     }
   }

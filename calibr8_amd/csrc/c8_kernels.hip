@@ -465,6 +465,7 @@ template <class E> static KernelSet kernel_set_for(int model) {
     case MODEL_HYPER_J2: return kernel_set<E, HyperJ2>();
     case MODEL_SMALL_HILL: return kernel_set<E, SmallHill>();
     case MODEL_ISOTROPIC_ELASTIC: return kernel_set<E, IsotropicElastic>();
+    case MODEL_HYPO_HILL: return kernel_set<E, HypoHill>();
   }
   return KernelSet{};
 }

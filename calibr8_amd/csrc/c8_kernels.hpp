@@ -7,7 +7,7 @@
 
 namespace c8 {
 
-enum { MODEL_NONE = -1, MODEL_ELASTIC = 0, MODEL_SMALL_J2 = 1, MODEL_HYPER_J2 = 2, MODEL_SMALL_HILL = 3, MODEL_ISOTROPIC_ELASTIC = 4 };
+enum { MODEL_NONE = -1, MODEL_ELASTIC = 0, MODEL_SMALL_J2 = 1, MODEL_HYPER_J2 = 2, MODEL_SMALL_HILL = 3, MODEL_ISOTROPIC_ELASTIC = 4, MODEL_HYPO_HILL = 5 };
 
 struct LaunchArgs {
   MeshTables mt;

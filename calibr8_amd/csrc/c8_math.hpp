@@ -106,6 +106,8 @@ C8_HD Dual c8_exp(Dual const& a) {
   return Dual(e, e * a.d);
 }
 C8_HD double c8_exp(double a) { return exp(a); }
+C8_HD Dual c8_abs(Dual const& a) { return a.v >= 0. ? a : Dual(-a.v, -a.d); }
+C8_HD double c8_abs(double a) { return fabs(a); }
 // pow(a, b) with both arguments differentiable (Sacado's rule: zero derivative at a == 0)
 C8_HD Dual c8_pow(Dual const& a, Dual const& b) {
   double const r = pow(a.v, b.v);
@@ -204,6 +206,61 @@ template <class T> C8_HD T norm(Tens3<T> const& A) {
               A.zx * A.zx + A.zy * A.zy + A.zz * A.zz;
   return c8_sqrt(s);
 }
+// minitensor::polar_rotation (Trilinos MiniTensor, third party): the rotation R of F = R U by Newton's iteration
+// X <- (mu X + X^-T / mu) / 2 with Higham's 1-norm / infinity-norm scaling, differentiated through like any other
+// arithmetic (global_residual.hpp:302-305 calls it on the FAD deformation gradient).  The trip count depends on
+// values only, so it is the same for every derivative slot of a point.
+template <class T> C8_HD T norm_1(Tens3<T> const& A) {  // largest absolute column sum
+  T const c0 = c8_abs(A.xx) + c8_abs(A.yx) + c8_abs(A.zx);
+  T const c1 = c8_abs(A.xy) + c8_abs(A.yy) + c8_abs(A.zy);
+  T const c2 = c8_abs(A.xz) + c8_abs(A.yz) + c8_abs(A.zz);
+  T best = c0;
+  if (val(c1) > val(best)) best = c1;
+  if (val(c2) > val(best)) best = c2;
+  return best;
+}
+template <class T> C8_HD T norm_infinity(Tens3<T> const& A) {  // largest absolute row sum
+  T const r0 = c8_abs(A.xx) + c8_abs(A.xy) + c8_abs(A.xz);
+  T const r1 = c8_abs(A.yx) + c8_abs(A.yy) + c8_abs(A.yz);
+  T const r2 = c8_abs(A.zx) + c8_abs(A.zy) + c8_abs(A.zz);
+  T best = r0;
+  if (val(r1) > val(best)) best = r1;
+  if (val(r2) > val(best)) best = r2;
+  return best;
+}
+template <class T> C8_HD double norm_val(Tens3<T> const& A) {  // value of the Frobenius norm
+  double const s = val(A.xx) * val(A.xx) + val(A.xy) * val(A.xy) + val(A.xz) * val(A.xz) + val(A.yx) * val(A.yx) +
+                   val(A.yy) * val(A.yy) + val(A.yz) * val(A.yz) + val(A.zx) * val(A.zx) + val(A.zy) * val(A.zy) +
+                   val(A.zz) * val(A.zz);
+  return sqrt(s);
+}
+template <class T> C8_HD Tens3<T> polar_rotation(Tens3<T> const& A) {
+  bool scaling = true;
+  double const tol_scale = 0.01;
+  double const sqrt_tol_conv = 1.9611031010039037e-08;  // sqrt(sqrt(3) * machine epsilon)
+  Tens3<T> X = A;
+  double gamma = 2.0;
+  C8_NOUNROLL
+  for (int num_iter = 0; num_iter < 128; ++num_iter) {
+    Tens3<T> const Y = inverse(X);
+    T mu = T(1.0);
+    if (scaling) {
+      mu = (norm_1(Y) * norm_infinity(Y)) / (norm_1(X) * norm_infinity(X));
+      mu = c8_sqrt(c8_sqrt(mu));
+    }
+    Tens3<T> const Z = scale(0.5, scale(mu, X) + scale(1. / mu, transpose(Y)));
+    Tens3<T> const D = Z - X;
+    double const nD = norm_val(D);
+    double const delta = nD / norm_val(Z);
+    if (scaling && delta < tol_scale) scaling = false;
+    bool const end_iter = nD <= sqrt_tol_conv || (delta > 0.5 * gamma && !scaling);
+    X = Z;
+    gamma = delta;
+    if (end_iter) break;
+  }
+  return X;
+}
+
 // symmetric tensor from the packed local-variable order (00,01,02,11,12,22)
 // (local_residual.cpp:206-216)
 template <class T> C8_HD Tens3<T> sym6(T const* s) {

@@ -261,6 +261,102 @@ template <class T> struct SmallHill {
   }
 };
 
+// ---- hypo_hill.cpp: hypoelastic rate form in the unrotated configuration (local unknown = unrotated Cauchy stress
+//      TC), Hill's yield function (yield_functions.hpp:34-99), Voce hardening --------------------------------------
+template <class T> struct HypoHill {
+  static constexpr int NLOC = 7, NPARAMS = 11;
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (hypo_hill.cpp:84-95)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // TC(00,01,02,11,12,22), alpha
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }  // :123-131
+  // the unrotated rate of deformation d = R^T sym((F - F_prev) F^-1) R depends on F and F_prev only
+  // (eval_d :134-139, hypo_kinematics.hpp:11-18; the reference caches it over the local Newton iteration, :150-151)
+  struct Trial { T d[6]; };
+  C8_HD Trial trial(PointState<T> const& g) const {
+    Tens3<T> const I = eye3<T>();
+    Tens3<T> const F = g.grad_u + I;
+    Tens3<T> const F_prev = g.grad_u_prev + I;
+    Tens3<T> const Rot = polar_rotation(F);
+    Tens3<T> const L = matmul(F - F_prev, inverse(F));
+    Tens3<T> const D = scale(0.5, L + transpose(L));
+    Trial t;
+    pack_sym6(matmul(matmul(transpose(Rot), D), Rot), t.d);
+    return t;
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // :153-168: elastic predictor, values only
+    double const E = val(params[0]), nu = val(params[1]);
+    double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+    Trial const t = trial(g);
+    double const ltr = lambda * (val(t.d[0]) + val(t.d[3]) + val(t.d[5]));
+    C8_UNROLL
+    for (int k = 0; k < 6; ++k) set_val(xi[k], val(xi_prev[k]) + 2. * mu * val(t.d[k]) + ((k == 0 || k == 3 || k == 5) ? ltr : 0.));
+    set_val(xi[6], val(xi_prev[6]));
+  }
+  C8_HD Tens3<T> rotated_cauchy(PointState<T> const& g) const {  // :292-298
+    Tens3<T> const Rot = polar_rotation(g.grad_u + eye3<T>());
+    return matmul(matmul(Rot, sym6(xi)), transpose(Rot));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const { return dev(rotated_cauchy(g)); }  // :313-316
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :301-310
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const { return trace(rotated_cauchy(g)) / 3.; }  // :319-322
+  // both at once (one polar decomposition instead of two); Mechanics::flux_coupled uses it when a model has it
+  C8_HD void cauchy_and_hydro(PointState<T> const& g, Tens3<T>& sigma, T& sigma_h) const {
+    Tens3<T> const RC = rotated_cauchy(g);
+    sigma_h = trace(RC) / 3.;
+    sigma = dev(RC);
+    sigma.xx = sigma.xx - g.p; sigma.yy = sigma.yy - g.p; sigma.zz = sigma.zz - g.p;
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {
+    return evaluate(g, abs_tol, trial(g), force_path, path_in);
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const& tr, bool force_path = false, int path_in = 0) {  // :211-289
+    T const lambda = compute_lambda(params[0], params[1]);
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[9], D = params[10];
+    auto inv2 = [](T const& r) { return 1. / (r * r); };
+    T const i00 = inv2(params[3]), i11 = inv2(params[4]), i22 = inv2(params[5]);
+    T const F = 0.5 * (i11 + i22 - i00), G = 0.5 * (i22 + i00 - i11), H = 0.5 * (i00 + i11 - i22);  // compute_hill_params
+    T const L = 1.5 * inv2(params[8]), M = 1.5 * inv2(params[7]), N = 1.5 * inv2(params[6]);
+    T const alpha = xi[6], alpha_old = xi_prev[6];
+    Tens3<T> const TC = sym6(xi);
+    T const d12 = TC.yy - TC.zz, d20 = TC.zz - TC.xx, d01 = TC.xx - TC.yy;
+    T const hill = c8_sqrt(F * d12 * d12 + G * d20 * d20 + H * d01 * d01 +
+                           2. * (L * TC.yz * TC.yz + M * TC.xz * TC.xz + N * TC.xy * TC.xy));  // compute_hill_value
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    Tens3<T> const d = sym6(tr.d);
+    T const ltr = lambda * trace(d);
+    Tens3<T> Rt = TC - sym6(xi_prev) - scale(2. * mu, d);
+    Rt.xx = Rt.xx - ltr; Rt.yy = Rt.yy - ltr; Rt.zz = Rt.zz - ltr;
+    Rt = scale(1. / val(mu), Rt);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      Tens3<T> n;  // compute_hill_normal
+      n.xx = ((G + H) * TC.xx - H * TC.yy - G * TC.zz) / hill;
+      n.yy = ((F + H) * TC.yy - H * TC.xx - F * TC.zz) / hill;
+      n.zz = ((G + F) * TC.zz - G * TC.xx - F * TC.yy) / hill;
+      n.xy = n.yx = N * TC.xy / hill;
+      n.xz = n.zx = M * TC.xz / hill;
+      n.yz = n.zy = L * TC.yz / hill;
+      T const dgam = alpha - alpha_old;
+      Rt = Rt + scale((2. * mu * dgam) / val(mu), n);
+      R[6] = f;
+    } else {
+      R[6] = alpha - alpha_old;
+    }
+    pack_sym6(Rt, R);
+    return path;
+  }
+};
+
 // ---- hyper_J2.cpp -------------------------------------------------------------
 template <class T> struct HyperJ2 {
   static constexpr int NLOC = 8, NPARAMS = 8;
@@ -371,15 +467,29 @@ template <class T> struct MechFlux {
   T Gp[3];      // multiplies grad N in the pressure residual
 };
 
+// optional member of a local model: Cauchy stress and its hydrostatic part from one evaluation
+template <class L, class T, class = void> struct has_stress_pair : std::false_type {};
+template <class L, class T>
+struct has_stress_pair<L, T, decltype(std::declval<L const&>().cauchy_and_hydro(std::declval<PointState<T> const&>(),
+                                                                              std::declval<Tens3<T>&>(), std::declval<T&>()))>
+    : std::true_type {};
+
 struct Mechanics {
   static constexpr bool USES_U = false;  // the integrand reads grad u, p, grad p but not u (mechanics.cpp:116-227)
   template <class T, class Local>
   C8_HD static void flux_coupled(Local const& local, PointState<T> const& g, double h, double stab_mult, MechFlux<T>& f) {
-    Tens3<T> stress = local.cauchy(g);
+    Tens3<T> stress;
+    T hydro;
+    if constexpr (has_stress_pair<Local, T>::value) {
+      local.cauchy_and_hydro(g, stress, hydro);
+    } else {
+      stress = local.cauchy(g);
+      hydro = local.hydro_cauchy(g);
+    }
     T const mu = compute_mu(local.params[0], local.params[1]);
     T const psf = local.pressure_scale_factor();
     T const tau = (stab_mult * 0.5 * h * h) / mu;  // mechanics.cpp:197
-    f.Vp = -(local.hydro_cauchy(g) / psf);
+    f.Vp = -(hydro / psf);
     if (Local::FINITE_DEF) {
       Tens3<T> const F = g.grad_u + eye3<T>();
       Tens3<T> const C = cofactor(F);

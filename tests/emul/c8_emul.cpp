@@ -205,6 +205,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "hyper_J2") run_qoi_wave<HyperJ2>(c);
     else if (model == "small_hill") run_qoi_wave<SmallHill>(c);
     else if (model == "isotropic_elastic") run_qoi_wave<IsotropicElastic>(c);
+    else if (model == "hypo_hill") run_qoi_wave<HypoHill>(c);
     else return -2;
     return 0;
   }
@@ -215,6 +216,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "hyper_J2") run_residual_wave<HyperJ2>(c);
     else if (model == "small_hill") run_residual_wave<SmallHill>(c);
     else if (model == "isotropic_elastic") run_residual_wave<IsotropicElastic>(c);
+    else if (model == "hypo_hill") run_residual_wave<HypoHill>(c);
     else return -2;
     return 0;
   }
@@ -225,6 +227,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "hyper_J2") run_wave_adjoint<HyperJ2>(c);
     else if (model == "small_hill") run_wave_adjoint<SmallHill>(c);
     else if (model == "isotropic_elastic") run_wave_adjoint<IsotropicElastic>(c);
+    else if (model == "hypo_hill") run_wave_adjoint<HypoHill>(c);
     else return -2;
     return 0;
   }
@@ -235,6 +238,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "hyper_J2") run_wave<HyperJ2>(c);
     else if (model == "small_hill") run_wave<SmallHill>(c);
     else if (model == "isotropic_elastic") run_wave<IsotropicElastic>(c);
+    else if (model == "hypo_hill") run_wave<HypoHill>(c);
     else return -2;
     return 0;
   }
@@ -243,6 +247,7 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
   else if (model == "hyper_J2") run<E, HyperJ2>(c);
   else if (model == "small_hill") run<E, SmallHill>(c);
   else if (model == "isotropic_elastic") run<E, IsotropicElastic>(c);
+  else if (model == "hypo_hill") run<E, HypoHill>(c);
   else return -2;
   return 0;
 }

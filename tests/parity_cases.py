@@ -17,9 +17,10 @@ EL = [1000.0, 0.25, 1e-3, 10.0]
 # small_hill: E nu Y R00 R11 R22 R01 R02 R12 S D (small_hill.cpp:78-88)
 HILL = [1000.0, 0.25, 2.0, 1.0, 1.1, 0.9, 1.05, 0.95, 1.0, 1.0, 50.0]
 CASES = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("elastic", EL, 0.002), ("hyper_J2", HJ2, 0.004),
-         ("small_hill", HILL, 0.004), ("isotropic_elastic", [1000.0, 0.25], 0.002)]
+         ("small_hill", HILL, 0.004), ("isotropic_elastic", [1000.0, 0.25], 0.002), ("hypo_hill", HILL, 0.004)]
 MESHES = ["hex8", "tet4"]
-ACTIVE = {"small_J2": [0, 1, 2, 3], "elastic": [0, 1], "hyper_J2": [0, 1, 2, 3, 4, 7], "small_hill": [0, 2, 3, 6, 9, 10], "isotropic_elastic": [0, 1]}
+ACTIVE = {"small_J2": [0, 1, 2, 3], "elastic": [0, 1], "hyper_J2": [0, 1, 2, 3, 4, 7], "small_hill": [0, 2, 3, 6, 9, 10], "isotropic_elastic": [0, 1],
+          "hypo_hill": [0, 2, 3, 6, 9, 10]}
 
 
 def mesh_of(kind, n=(4, 3, 3)):

@@ -31,7 +31,7 @@ def random_case(seed):
     # perturbed parameters (+-20 %), kept admissible
     p = np.array(PARAMS[model], dtype=np.float64)
     p = p * (1.0 + 0.2 * (rng.random(len(p)) - 0.5) * (np.abs(p) > 0))
-    if model in ("elastic", "small_J2", "hyper_J2", "small_hill", "isotropic_elastic"):
+    if model in ("elastic", "small_J2", "hyper_J2", "small_hill", "isotropic_elastic", "hypo_hill"):
         p[1] = min(p[1], 0.4)  # Poisson's ratio
     return model, list(p), kind, c, conn, eps, scatter, kernel
 

@@ -112,7 +112,7 @@ def test_reference_regressions_with_device_newton_driver(deck):
     assert abs(pr.qoi() / expected - 1) < tol, (pr.qoi(), pr.newton_iters)
 
 
-@pytest.mark.parametrize("deck", ["notch_small_J2", "notch_hyper_J2"])
+@pytest.mark.parametrize("deck", ["notch_small_J2", "notch_hyper_J2", "notch_hypo_J2"])
 def test_notch_regressions_with_device_newton_driver(deck):
     # the reference's 3-D notch decks (1550 tets read out of test/mesh/notch/notch0.smb, tests/golden/make_notch_fixture.py),
     # four plastic load steps, every assembly, boundary condition and Newton update on the device.  `notch_small_J2`
@@ -127,6 +127,10 @@ def test_notch_regressions_with_device_newton_driver(deck):
         asm = Assembler(4, c, conn, "small_hill", [1000.0, 0.25, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 10.0, 2.0], max_iters=500)
         pr = PrimalDriver(asm, sym + [(0, 1, ns["ymax"], lambda x, y, z, t: 0.001 * t)]).solve(4)
         expected = 1.4622046563394649e-04
+    elif deck == "notch_hypo_J2":  # selects `hypo_hill` (notch_hypo_J2.yaml.in:21); the oracle reproduces the pin to 1.4e-11
+        asm = Assembler(4, c, conn, "hypo_hill", [1000.0, 0.25, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 10.0, 2.0], max_iters=500)
+        pr = PrimalDriver(asm, sym + [(0, 1, ns["ymax"], lambda x, y, z, t: 0.005 * t)]).solve(4)
+        expected = 7.5441386985803955e-04
     else:
         asm = Assembler(4, c, conn, "hyper_J2", [1000.0, 0.25, 10.0, 0.0, 0.0, 0.0, 0.0, 100.0], max_iters=500)
         pr = PrimalDriver(asm, sym + [(0, 1, ns["ymax"], lambda x, y, z, t: 0.005 * t)]).solve(4)

@@ -62,7 +62,8 @@ def test_shape_partition_of_unity_and_gradients():
                                               ("elastic", [1000.0, 0.25, 1e-3, 10.0], 0.002),
                                               ("hyper_J2", [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0], 0.004),
                                               ("small_hill", [1000.0, 0.25, 2.0, 1.0, 1.1, 0.9, 1.05, 0.95, 1.0, 1.0, 50.0], 0.004),
-                                              ("isotropic_elastic", [1000.0, 0.25], 0.002)])
+                                              ("isotropic_elastic", [1000.0, 0.25], 0.002),
+                                              ("hypo_hill", [1000.0, 0.25, 2.0, 1.0, 1.1, 0.9, 1.05, 0.95, 1.0, 1.0, 50.0], 0.004)])
 def test_jacobian_matches_finite_differences_hex8(model, params, eps):
     c, conn, sets = brick(3, 2, 2, 1.0, 0.8, 0.7)
     c = jiggle(c, sets, 0.05)
@@ -77,7 +78,7 @@ def test_jacobian_matches_finite_differences_hex8(model, params, eps):
         return np.concatenate(ls.b), ls, xi
 
     R, ls, xi = resid(u, p)
-    if model in ("small_J2", "small_hill"):
+    if model in ("small_J2", "small_hill", "hypo_hill"):
         frac = (xi[:, :, 6] > 0).mean()
         assert (frac > 0.2) if eps > 0.003 else (frac == 0.0)
     A = block_matrix(be, ls).toarray()

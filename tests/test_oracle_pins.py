@@ -110,6 +110,17 @@ def test_notch_hyper_J2(notch):
     assert pr.xi[-1][:, :, 7].max() > 1e-4
 
 
+def test_notch_hypo_J2_deck_is_hypo_hill(notch):
+    # primal/notch_hypo_J2.yaml.in: `hypo_hill` (:21) with R = 1, Y 2, S 10, D 2, 4 steps, ymax pulled by 0.005*t; pin :50-51.
+    # Exercises the polar rotation (minitensor::polar_rotation, restated) and the unrotated rate of deformation.
+    be = ol.Oracle(ol.TET4, notch["coords"], notch["conn"], "hypo_hill",
+                   [1000.0, 0.25, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 10.0, 2.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    dbcs = sym_dbcs(notch) + [Dbc(0, 1, notch["node_sets"]["ymax"], lambda x, y, z, t: 0.005 * t)]
+    pr = Primal(be, notch["coords"], dbcs, max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 7.5441386985803955e-04) < 1.0e-9  # deck tolerance 1e-4; measured 1.4e-11
+    assert pr.xi[-1][:, :, 6].max() > 1e-2
+
+
 def test_baseline_config1_hex8_elastic_bar():
     # BASELINE.json configs[0] (SURVEY.md 8d "Config 1 (plumbing)"): 10 x 10 x 10 hex8 unit bar, `elastic` with the
     # material of cube_elastic.yaml.in:21-27, symmetric BCs on xmin/ymin/zmin: free thermal expansion,

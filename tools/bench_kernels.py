@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--edge", type=int, default=100)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--scatter", default="atomic")
-    ap.add_argument("--model", default="small_J2", choices=["small_J2", "hyper_J2", "small_hill", "elastic"])
+    ap.add_argument("--model", default="small_J2", choices=["small_J2", "hyper_J2", "small_hill", "elastic", "hypo_hill"])
     ap.add_argument("--tet", action="store_true", help="split every hex into 6 tet4 (the reference's element type)")
     args = ap.parse_args()
     import torch
@@ -36,7 +36,7 @@ def main():
         assert (vol > 0).all()
         et = 4
     from parity_cases import ACTIVE, EL, HILL, HJ2
-    params = {"small_J2": J2, "hyper_J2": HJ2, "small_hill": HILL, "elastic": EL}[args.model]
+    params = {"small_J2": J2, "hyper_J2": HJ2, "small_hill": HILL, "elastic": EL, "hypo_hill": HILL}[args.model]
     asm = Assembler(et, coords, conn, args.model, params, scatter=args.scatter)
     asm.set_active(0, ACTIVE[args.model][:4])
     asm.set_async(True)
