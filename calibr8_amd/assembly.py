@@ -150,6 +150,10 @@ class Assembler:
         m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC, "gather": _l.C8_SCATTER_GATHER}[mode]
         _l.check(self.L.c8_set_scatter_mode(self.h, m))
 
+    def set_shape_cache(self, on):
+        """cached shape tables of the hex8 wave kernels (default on; 1.7 KB per element)"""
+        _l.check(self.L.c8_set_shape_cache(self.h, int(bool(on))))
+
     def set_stage_chunk(self, min_chunk):
         """scatter='gather': smallest chunk of elements staged at a time (default 8192)"""
         _l.check(self.L.c8_set_stage_chunk(self.h, int(min_chunk)))

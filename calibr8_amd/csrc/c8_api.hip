@@ -129,14 +129,42 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
     c8_destroy(c);
     return fail(C8_ERR_DEVICE, "c8_create: status allocation failed");
   }
+  rc = c8_set_shape_cache(c, 1);
+  if (rc) { c8_destroy(c); return rc; }
   *out = c;
+  return C8_OK;
+}
+
+// The geometry of a context is static: dN/dx, w dv and the element size of every element are computed once and read
+// back by the wave kernels (1.7 KB per hex8 element) instead of being recomputed by every call.  on = 0 frees the
+// tables (the kernels then compute them per call, same values); element types without wave kernels have none.
+int c8_set_shape_cache(c8_ctx* c, int on) {
+  if (!c) return fail(C8_ERR_ARG, "c8_set_shape_cache: null ctx");
+  if (!on || !c->ks.shape_tables) {
+    (void)hipFree(c->d_shape);
+    c->d_shape = nullptr;
+    return C8_OK;
+  }
+  if (c->d_shape) return C8_OK;
+  size_t const bytes = (size_t)c->mesh.nelems * c->ks.shape_stride * sizeof(double);
+  if (bytes == 0) return C8_OK;
+  if (hipMalloc((void**)&c->d_shape, bytes) != hipSuccess) {
+    c->d_shape = nullptr;
+    return fail(C8_ERR_DEVICE, "c8_set_shape_cache: cannot allocate the shape tables (c8_set_shape_cache(ctx, 0) runs without them)");
+  }
+  MeshTables const mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params};
+  if (c->ks.shape_tables(mt, c->d_shape, c->mesh.nelems, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+    (void)hipFree(c->d_shape);
+    c->d_shape = nullptr;
+    return fail(C8_ERR_DEVICE, "c8_set_shape_cache: shape-table kernel failed");
+  }
   return C8_OK;
 }
 
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
   stage_release(c);
-  void* bufs[] = {c->d_cal_faces, c->d_cal_S, c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
+  void* bufs[] = {c->d_shape, c->d_cal_faces, c->d_cal_S, c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
@@ -245,7 +273,7 @@ int c8_status(c8_ctx* c) {
 }  // extern "C"
 
 static MeshTables tables(c8_ctx const* c, bool colored) {
-  return MeshTables{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, colored ? c->d_order : nullptr, c->d_params};
+  return MeshTables{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, colored ? c->d_order : nullptr, c->d_params, c->d_shape};
 }
 
 // Staged (gather) assembly on the caller's stream: chunk k of the elements is assembled into the stage ring,

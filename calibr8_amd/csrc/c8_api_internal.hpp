@@ -40,6 +40,7 @@ struct c8_ctx {
   int32_t* d_node_order = nullptr;
   c8::StagePlan plan;                 // staged assembly: chunks, ring, node order
   int stage_min_chunk = 0;            // 0: automatic (c8_api.hip: stage_setup)
+  double* d_shape = nullptr;          // cached shape tables of the wave kernels, [nelems][ks.shape_stride] (hex8; null: computed per call)
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
   int* d_status = nullptr;

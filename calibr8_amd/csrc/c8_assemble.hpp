@@ -41,6 +41,9 @@ struct MeshTables {
   int32_t const* elem_set;   // [nelems] or null (single set)
   int32_t const* order;      // element processing order (colour-sorted) or null
   double const* params;      // [nsets][NPARAMS]
+  // cached shape tables of the wave kernels (hex8), [nelems][SHAPE_STRIDE], or null: the geometry is static, so
+  // dN/dx, w dv and the element size are computed once per context (store_shape_tables) instead of per call
+  double const* shape = nullptr;
 };
 struct ModelSettings {
   double stab_mult;

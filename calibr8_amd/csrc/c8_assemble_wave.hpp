@@ -34,6 +34,66 @@ namespace c8 {
 constexpr int WQ = 16;   // point quantities: grad_u (0..8 row-major), p (9), grad_p (10..12), u (13..15)
 constexpr int WF = 13;   // point fluxes: Gu (0..8 row-major), Vp (9), Gp (10..12)
 
+// ---- cached shape tables (static geometry) --------------------------------------------------------------------
+// Per element: dN[pt][n][3] (lane = pt*8 + n reads its three values contiguously), w dv [pt], element size h.
+constexpr int SHAPE_STRIDE = 208;  // 192 + 8 + 1, padded to a multiple of 64 bytes
+constexpr int SHAPE_WDV = 192, SHAPE_H = 200;
+template <class E> struct ShapeShared {
+  double X[E::NN][3];
+  double N[E::NP0][E::NN];
+  double dN[E::NP0][E::NN][3];
+  double wdv[E::NP0];
+  double h;
+};
+struct ShapeLane {};
+// one wavefront per element, the arithmetic of the kernels' own shape phase (shape_entry, elem_size)
+template <class E, class EX> C8_HD void store_shape_tables(EX& ex, ShapeShared<E>& sh, MeshTables const& mt, double* tab, int e) {
+  static_assert(E::NN == 8 && E::NP0 == 8, "hex8-like element");
+  ex.each([&](int lane) {
+    if (lane < 3 * E::NN) {
+      int const n = lane / 3, d = lane - 3 * n;
+      sh.X[n][d] = mt.coords[(size_t)mt.conn[e * E::NN + n] * 3 + d];
+    }
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
+    if (lane == 0) sh.h = elem_size<E>(sh);
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    double* const t = tab + (size_t)e * SHAPE_STRIDE;
+    int const pt = lane >> 3, n = lane & 7;
+    t[lane * 3 + 0] = sh.dN[pt][n][0];
+    t[lane * 3 + 1] = sh.dN[pt][n][1];
+    t[lane * 3 + 2] = sh.dN[pt][n][2];
+    if (lane < E::NP0) t[SHAPE_WDV + lane] = sh.wdv[lane];
+    if (lane == E::NP0) t[SHAPE_H] = sh.h;
+    if (lane > E::NP0 && lane < SHAPE_STRIDE - SHAPE_H + E::NP0) t[SHAPE_H + lane - E::NP0] = 0.;  // padding
+  });
+  ex.sync();
+}
+// the lane's share of the cached tables: issued with the first loads of an element ...
+template <class E, class R> C8_HD void load_cached_shape(R& r, MeshTables const& mt, int e, int lane) {
+  double const* const t = mt.shape + (size_t)e * SHAPE_STRIDE;
+  r.dn[0] = t[lane * 3 + 0];
+  r.dn[1] = t[lane * 3 + 1];
+  r.dn[2] = t[lane * 3 + 2];
+  r.sx = (lane <= E::NP0) ? t[SHAPE_WDV + lane] : 0.;  // lanes 0..7: w dv of point `lane`; lane 8: h
+}
+// ... and committed to LDS beside the nodal data (N is a constant of the reference element)
+template <class E, class R, class SH> C8_HD void commit_cached_shape(R const& r, SH& sh, int lane) {
+  int const pt = lane >> 3, n = lane & 7;
+  double xi[3], w;
+  E::point(0, pt, xi, w);
+  sh.N[pt][n] = E::N(n, xi);
+  sh.dN[pt][n][0] = r.dn[0];
+  sh.dN[pt][n][1] = r.dn[1];
+  sh.dN[pt][n][2] = r.dn[2];
+  if (lane < E::NP0) sh.wdv[lane] = r.sx;
+  if (lane == E::NP0) sh.h = r.sx;
+}
+
 template <class E, int NL> struct WaveShared {
   static constexpr int NLP = 8;  // lanes per point in phase N
   double X[E::NN][3];
@@ -75,6 +135,7 @@ template <template <class> class ModelT> struct WaveLane {
   // be exposed after the shape tables and in front of the scatter)
   double xi_pre, xip_pre;
   unsigned long long pos8;
+  double dn[3], sx;  // cached shape tables: this lane's dN/dx entry; w dv (lanes 0..7) or h (lane 8)
   int iter;
   double R_norm_0;
   bool converged, failed;
@@ -107,6 +168,23 @@ C8_HD void seed_q(PointState<Dual>& g, int c) {
 }
 
 // interpolated value of point quantity c at point pt (global_residual.cpp:289-332)
+// The 16 point quantities are the 4 x 4 products (nodal value a) x (shape entry b) summed over the nodes:
+//   a in {u_0, u_1, u_2, p},  b in {dN/dx_0, dN/dx_1, dN/dx_2, N};  q index: grad_u[a][b] = 3a+b, p = 9 (a=b=3),
+//   grad_p[b] = 10+b (a=3), u[a] = 13+a (b=3).
+// One code path for every lane (the index only selects base address and stride of the two LDS operands); same operand
+// order and the same sequential sum over the nodes as interp_q.
+C8_HD int q_index(int a, int b) { return (a < 3) ? ((b < 3) ? 3 * a + b : 13 + a) : ((b < 3) ? 10 + b : 9); }
+template <class E, class SH>
+C8_HD double interp_ab(SH const& sh, int pt, int a, int b, double const* u3 /* [NN][3] */, double const* p1 /* [NN] */) {
+  double const* const Ap = (a < 3) ? u3 + a : p1;
+  int const sa = (a < 3) ? 3 : 1;
+  double const* const Bp = (b < 3) ? &sh.dN[pt][0][b] : &sh.N[pt][0];
+  int const sb = (b < 3) ? 3 : 1;
+  double s = 0.;
+  C8_UNROLL
+  for (int n = 0; n < E::NN; ++n) s += Ap[n * sa] * Bp[n * sb];
+  return s;
+}
 template <class E, class SH> C8_HD double interp_q(SH const& sh, int pt, int c, bool prev) {
   double s = 0.;
   if (c < 9) {
@@ -211,13 +289,14 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       int ib, nb, eqb;
       slot_to_dof<E>(lane & 31, ib, nb, eqb);
       r.pos8 = *reinterpret_cast<unsigned long long const*>(mt.pos + ((size_t)e * E::NN + nb) * E::NN);  // pos[e][col node nb][0..7]
+      if (mt.shape) load_cached_shape<E>(r, mt, e, lane);
     }
     if (lane < E::NDOF) {
       int i, n, eq;
       slot_to_dof<E>(lane, i, n, eq);
       int const node = mt.conn[e * E::NN + n];
       if (i == 0) {
-        sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
+        if (!mt.shape) sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];  // only the shape tables read the coordinates
         sh.u[n][eq] = fa.u[(size_t)node * 3 + eq];
         if (PREV) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * 3 + eq];
       } else {
@@ -228,21 +307,30 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
         sh.deg[n] = mt.nodeptr[node + 1] - a;
       }
     }
+    if (mt.shape) commit_cached_shape<E>(r, sh, lane);
   });
   ex.sync();
-  ex.each([&](int lane) {
-    shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
-    if (lane == 0) sh.h = elem_size<E>(sh);
-  });
-  ex.sync();
+  C8_STAMP(10);
+  if (!mt.shape) {
+    ex.each([&](int lane) {
+      shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
+      if (lane == 0) sh.h = elem_size<E>(sh);
+    });
+    ex.sync();
+  }
+  C8_STAMP(11);
   // ---- interpolation: lane (pt, d) computes quantities 2d and 2d+1 (and grad_u_prev) --------------
   ex.each([&](int lane) {
     int const pt = lane >> 3, d = lane & 7;
-    sh.q[pt][2 * d] = interp_q<E>(sh, pt, 2 * d, false);
-    sh.q[pt][2 * d + 1] = interp_q<E>(sh, pt, 2 * d + 1, false);
-    if (PREV) {
-      sh.qprev[pt][d] = interp_q<E>(sh, pt, d, true);
-      if (d == 0) sh.qprev[pt][8] = interp_q<E>(sh, pt, 8, true);
+    {
+      int const k0 = 2 * d, k1 = 2 * d + 1;  // products (a, b) = (k >> 2, k & 3)
+      sh.q[pt][q_index(k0 >> 2, k0 & 3)] = interp_ab<E>(sh, pt, k0 >> 2, k0 & 3, &sh.u[0][0], &sh.p[0]);
+      sh.q[pt][q_index(k1 >> 2, k1 & 3)] = interp_ab<E>(sh, pt, k1 >> 2, k1 & 3, &sh.u[0][0], &sh.p[0]);
+    }
+    if (PREV) {  // grad_u at the previous step: entry d = (a, b) with a = d / 3 (and entry 8 on lane d = 0)
+      int const a = (d >= 3) + (d >= 6), b = d - 3 * a;
+      sh.qprev[pt][d] = interp_ab<E>(sh, pt, a, b, &sh.u_prev[0][0], &sh.p[0]);
+      if (d == 0) sh.qprev[pt][8] = interp_ab<E>(sh, pt, 2, 2, &sh.u_prev[0][0], &sh.p[0]);
     }
     if (d < NL) {
       auto& r = ex.lane(lane);
@@ -747,6 +835,7 @@ template <template <class> class ModelT> struct WaveLaneA {
   double acc;
   int slot;
   double xi_pre, xip_pre;  // local state of this lane's (point, direction), loaded with the first loads of the element
+  double dn[3], sx;        // cached shape tables: this lane's dN/dx entry; w dv (lanes 0..7) or h (lane 8)
 };
 
 // interpolate the adjoint nodal values like the point quantities (same B matrix)
@@ -790,13 +879,14 @@ C8_HD void wave_prologue(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& 
         r.xip_pre = fa.xi_prev[q + d];
         r.xi_pre = fa.xi[q + d];
       }
+      if (mt.shape) load_cached_shape<E>(r, mt, e, lane);
     }
     if (lane < E::NDOF) {
       int i, n, eq;
       slot_to_dof<E>(lane, i, n, eq);
       int const node = mt.conn[e * E::NN + n];
       if (i == 0) {
-        sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
+        if (!mt.shape) sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];  // only the shape tables read the coordinates
         sh.u[n][eq] = fa.u[(size_t)node * 3 + eq];
         if (PREV) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * 3 + eq];
         sh.z[lane] = aa.z_u[(size_t)node * 3 + eq];
@@ -806,22 +896,30 @@ C8_HD void wave_prologue(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& 
         sh.z[lane] = aa.z_p[node];
       }
     }
+    if (mt.shape) commit_cached_shape<E>(ex.lane(lane), sh, lane);
   });
   ex.sync();
-  ex.each([&](int lane) {
-    shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
-    if (lane == 0) sh.h = elem_size<E>(sh);
-  });
-  ex.sync();
+  if (!mt.shape) {
+    ex.each([&](int lane) {
+      shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
+      if (lane == 0) sh.h = elem_size<E>(sh);
+    });
+    ex.sync();
+  }
   ex.each([&](int lane) {
     int const pt = lane >> 3, d = lane & 7;
-    sh.q[pt][2 * d] = interp_q<E>(sh, pt, 2 * d, false);
-    sh.q[pt][2 * d + 1] = interp_q<E>(sh, pt, 2 * d + 1, false);
-    sh.zq[pt][2 * d] = interp_zq<E>(sh, pt, 2 * d);
-    sh.zq[pt][2 * d + 1] = interp_zq<E>(sh, pt, 2 * d + 1);
+    C8_UNROLL
+    for (int h = 0; h < 2; ++h) {
+      int const k = 2 * d + h, a = k >> 2, b = k & 3;  // product (a, b), see interp_ab
+      sh.q[pt][q_index(a, b)] = interp_ab<E>(sh, pt, a, b, &sh.u[0][0], &sh.p[0]);
+      // the adjoint nodal values, same products (z = [u part: 3n+i | p part: 3 NN + n]); u[a] has no adjoint twin
+      double const zv = interp_ab<E>(sh, pt, a, b, &sh.z[0], &sh.z[3 * E::NN]);
+      sh.zq[pt][q_index(a, b)] = (a < 3 && b == 3) ? 0. : zv;
+    }
     if (PREV) {
-      sh.qprev[pt][d] = interp_q<E>(sh, pt, d, true);
-      if (d == 0) sh.qprev[pt][8] = interp_q<E>(sh, pt, 8, true);
+      int const a = (d >= 3) + (d >= 6), b = d - 3 * a;
+      sh.qprev[pt][d] = interp_ab<E>(sh, pt, a, b, &sh.u_prev[0][0], &sh.p[0]);
+      if (d == 0) sh.qprev[pt][8] = interp_ab<E>(sh, pt, 2, 2, &sh.u_prev[0][0], &sh.p[0]);
     }
     if (d < NL) {
       auto& r = ex.lane(lane);

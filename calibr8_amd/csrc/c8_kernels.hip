@@ -225,6 +225,21 @@ template <class E, template <class> class ModelT> static hipError_t launch_param
   return hipGetLastError();
 }
 
+// cached shape tables of the wave kernels: one wavefront per element, once per context
+template <class E> __global__ void __launch_bounds__(64) k_shape_tables(MeshTables mt, double* tab, int nelems) {
+  __shared__ ShapeShared<E> sh;
+  int const e = blockIdx.x;
+  if (e >= nelems) return;
+  ShapeLane L;
+  GpuExec<ShapeLane> ex(threadIdx.x, L);
+  store_shape_tables<E>(ex, sh, mt, tab, e);
+}
+template <class E> static hipError_t launch_shape_tables(MeshTables const& mt, double* tab, int nelems, hipStream_t stream) {
+  if (nelems <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_shape_tables<E>), dim3(nelems), dim3(64), 0, stream, mt, tab, nelems);
+  return hipGetLastError();
+}
+
 // K2 for hex8: eight elements per wavefront, 32 per workgroup (residual_wave8)
 template <class E, template <class> class ModelT>
 __global__ void __launch_bounds__(BLOCK, 2) k_residual_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
@@ -427,6 +442,7 @@ template <class E, template <class> class ModelT> struct WaveKernel {
   static LaunchFn get_param_gradient() { return nullptr; }
   static LaunchFn get_residual() { return nullptr; }
   static LaunchFn get_qoi() { return nullptr; }
+  static constexpr hipError_t (*shape_tables)(MeshTables const&, double*, int, hipStream_t) = nullptr;
 };
 template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT> {
   static LaunchFn get() { return &launch_forward_wave<Elem<C8_HEX8>, ModelT>; }
@@ -435,6 +451,7 @@ template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT
   static LaunchFn get_param_gradient() { return &launch_param_gradient_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_residual() { return &launch_residual_wave<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_qoi() { return &launch_qoi_wave<Elem<C8_HEX8>, ModelT>; }
+  static constexpr hipError_t (*shape_tables)(MeshTables const&, double*, int, hipStream_t) = &launch_shape_tables<Elem<C8_HEX8>>;
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
@@ -451,6 +468,8 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.param_gradient = &launch_param_gradient<E, ModelT>;
   ks.qoi = WaveKernel<E, ModelT>::get_qoi() ? WaveKernel<E, ModelT>::get_qoi() : &launch_qoi<E, ModelT>;
   ks.qoi_slot = &launch_qoi<E, ModelT>;
+  ks.shape_tables = WaveKernel<E, ModelT>::shape_tables;
+  ks.shape_stride = SHAPE_STRIDE;
   ks.gather_rows = &launch_gather_rows<E>;
   ks.stage_stride = stage_stride<E>();
   ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements

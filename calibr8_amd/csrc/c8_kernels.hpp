@@ -35,6 +35,8 @@ struct KernelSet {
   LaunchFn param_gradient_wave;    // K5, one wavefront per element (hex8 only, else null)
   LaunchFn qoi;                // K6 (hex8: eight elements per wavefront)
   LaunchFn qoi_slot;           // K6, one lane per point of a lane group (any element type)
+  hipError_t (*shape_tables)(MeshTables const&, double* tab, int nelems, hipStream_t);  // cached shape tables of the wave kernels (hex8, else null)
+  int shape_stride;            // doubles per element in that table
   GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage
   int stage_stride;            // doubles per element in the stage
   bool adjoint_slot_stages;    // the slot-per-lane K3 can store into the stage (it transposes through LDS first)

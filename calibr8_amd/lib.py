@@ -97,6 +97,7 @@ SYMBOLS = [
     ("c8_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("c8_set_scatter_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_stage_chunk", C.c_int, [C.c_void_p, C.c_int]),
+    ("c8_set_shape_cache", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_kernel_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_async", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_status", C.c_int, [C.c_void_p]),

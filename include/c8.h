@@ -120,6 +120,10 @@ int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_COLORED (default),
  * smaller than the element bandwidth of the mesh) through a ring of three chunks.  Default: the whole mesh in one
  * chunk while its stage stays under 12 GB (8.4 KB per hex8, 2.2 KB per tet4 element), else chunks of 262144. */
 int c8_set_stage_chunk(c8_ctx* ctx, int min_chunk);
+/* Shape-table cache (default on; hex8 wave kernels): the geometry of a context is static, so dN/dx, w dv and the element
+ * size are computed once at c8_create (1.7 KB per element) instead of by every call (weight.cpp:5-25 recomputes them for
+ * every AD pass).  on = 0 frees the tables; results are the same either way. */
+int c8_set_shape_cache(c8_ctx* ctx, int on);
 /* Forward-assembly kernel: C8_KERNEL_SLOT = one lane group per element (any element type);
  * C8_KERNEL_WAVE = one wavefront per element (hex8); C8_KERNEL_AUTO picks WAVE where available. */
 int c8_set_kernel_variant(c8_ctx* ctx, int variant);

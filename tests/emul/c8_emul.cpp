@@ -65,6 +65,8 @@ extern "C" void c8emu_set_measured(int n, double const* u_meas, double load_meas
 }
 extern "C" void c8emu_qoi_info(double* out) { out[0] = g_qoi.area; out[1] = g_qoi.total_load; out[2] = g_qoi.load_mismatch; }
 
+static int g_shape_cache = 1;  // the wave kernels read cached shape tables (c8_set_shape_cache) or compute them per call
+extern "C" void c8emu_set_shape_cache(int on) { g_shape_cache = on; }
 static int g_last_nchunks = 0;
 extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
 
@@ -278,6 +280,17 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   c.nchunks_out = &g_last_nchunks;
   c.nelems = nelems;
   c.mt = MeshTables{mesh.conn.data(), mesh.coords.data(), graph.nodeptr.data(), graph.pos.data(), elem_set, nullptr, params};
+  std::vector<double> shape_tab;
+  if (g_shape_cache && elem_type == C8_HEX8) {  // what c8_set_shape_cache builds at c8_create, same source
+    using E8 = Elem<C8_HEX8>;
+    shape_tab.assign((size_t)nelems * SHAPE_STRIDE, 0.);
+    auto* ssh = new ShapeShared<E8>();
+    auto* sex = new CpuExec<ShapeLane, 64>();
+    for (int e = 0; e < nelems; ++e) store_shape_tables<E8>(*sex, *ssh, c.mt, shape_tab.data(), e);
+    delete sex;
+    delete ssh;
+    c.mt.shape = shape_tab.data();
+  }
   c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
   c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
   c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};

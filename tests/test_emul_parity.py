@@ -60,6 +60,20 @@ def test_adjoint_chain_wave_kernel(model, params, eps):
     check_adjoint_chain(orc, dut, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", [CASES[1], CASES[3]])
+def test_wave_kernels_without_shape_cache(model, params, eps):
+    # the wave kernels read dN/dx, w dv and h from tables built once per context (c8_set_shape_cache, default and the
+    # path every other test here takes); without the tables they compute them per element: same results
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.wave = True
+    em.lib().c8emu_set_shape_cache(0)
+    try:
+        check_forward(orc, dut, c, model, eps, TOL)
+        check_adjoint_chain(orc, dut, c, model, eps, TOL)
+    finally:
+        em.lib().c8emu_set_shape_cache(1)
+
+
 @pytest.mark.parametrize("model,params,eps", CASES)
 def test_staged_gather_assembly(model, params, eps):
     # staged assembly: element matrices stored element-major, rows summed per node (gather_node_rows)

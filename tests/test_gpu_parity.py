@@ -145,6 +145,17 @@ def test_staged_gather_assembly_tet4(model, params, eps):
     check_adjoint_chain(orc, gpu, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", [CASES[1], CASES[3]])
+def test_wave_kernels_without_shape_cache(model, params, eps):
+    # c8_set_shape_cache(ctx, 0): the wave kernels compute the shape tables per call instead of reading the cached ones
+    orc, gpu, c = make_pair(factory("atomic", "wave"), "hex8", model, params)
+    gpu.asm.set_shape_cache(False)
+    check_forward(orc, gpu, c, model, eps, TOL)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+    gpu.asm.set_shape_cache(True)
+    check_forward(orc, gpu, c, model, eps, TOL)
+
+
 def test_staged_gather_slot_kernel_hex8():
     orc, gpu, c = make_pair(factory("gather", "slot"), "hex8", "small_J2", J2)
     check_forward(orc, gpu, c, "small_J2", 0.004, TOL)

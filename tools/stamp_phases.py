@@ -15,7 +15,7 @@ from meshes import prescribed_fields
 J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
 n = 100
 coords, conn = brick_mesh(n, n, n)
-asm = Assembler(8, coords, conn, "small_J2", J2, scatter="atomic")
+asm = Assembler(8, coords, conn, "small_J2", J2, scatter=sys.argv[1] if len(sys.argv) > 1 else "atomic")
 u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
 u, p = asm.dev(u_h), asm.dev(p_h)
 u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
@@ -28,16 +28,16 @@ import ctypes as C
 buf = np.zeros(4096 * 16, dtype=np.uint64)
 asm.L.c8_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 asm.L.c8_debug_stamps(asm.h, buf.ctypes.data_as(C.c_void_p))
-raw = buf.reshape(4096, 16)[:, :10].astype(np.int64)
+raw = buf.reshape(4096, 16)[:, [0, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8, 9]].astype(np.int64)  # stamps in program order
 d = np.diff(raw, axis=1)
-names = ["load+shape+interp", "newton", "inverse", "D pass0", "P pass0", "D pass1", "P pass1", "(loop end)", "scatter"]
+names = ["loads (conn, then nodal)", "shape tables", "interpolation", "newton", "inverse", "D pass0", "P pass0", "D pass1", "P pass1", "(loop end)", "scatter"]
 plastic = (xi[::244][:4096, :, 6] > 0).any(dim=1).cpu().numpy()
-ok = raw[:, 9] > raw[:, 0]
+ok = raw[:, 11] > raw[:, 0]
 raw, d, plastic = raw[ok], d[ok], plastic[ok]
 for label, sel in (("all", np.ones(len(raw), bool)), ("elastic elems", ~plastic), ("plastic elems", plastic)):
     if sel.sum() == 0:
         continue
-    tot = (raw[sel, 9] - raw[sel, 0]).mean()
+    tot = (raw[sel, 11] - raw[sel, 0]).mean()
     print("%s (%d): total %.0f cycles" % (label, sel.sum(), tot))
     for k, nm in enumerate(names):
         print("   %-20s %8.0f  %5.1f %%" % (nm, d[sel, k].mean(), 100 * d[sel, k].mean() / tot))
