@@ -167,12 +167,12 @@ C8_HD void seed_q(PointState<Dual>& g, int c) {
   g.u[0].d = (c == 13) ? 1. : 0.; g.u[1].d = (c == 14) ? 1. : 0.; g.u[2].d = (c == 15) ? 1. : 0.;
 }
 
-// interpolated value of point quantity c at point pt (global_residual.cpp:289-332)
-// The 16 point quantities are the 4 x 4 products (nodal value a) x (shape entry b) summed over the nodes:
+// interpolated point quantities (global_residual.cpp:289-332).  The 16 point quantities are the 4 x 4 products
+// (nodal value a) x (shape entry b) summed over the nodes:
 //   a in {u_0, u_1, u_2, p},  b in {dN/dx_0, dN/dx_1, dN/dx_2, N};  q index: grad_u[a][b] = 3a+b, p = 9 (a=b=3),
 //   grad_p[b] = 10+b (a=3), u[a] = 13+a (b=3).
 // One code path for every lane (the index only selects base address and stride of the two LDS operands); same operand
-// order and the same sequential sum over the nodes as interp_q.
+// order and the same sequential sum over the nodes as the reference's loop.
 C8_HD int q_index(int a, int b) { return (a < 3) ? ((b < 3) ? 3 * a + b : 13 + a) : ((b < 3) ? 10 + b : 9); }
 template <class E, class SH>
 C8_HD double interp_ab(SH const& sh, int pt, int a, int b, double const* u3 /* [NN][3] */, double const* p1 /* [NN] */) {
@@ -183,24 +183,6 @@ C8_HD double interp_ab(SH const& sh, int pt, int a, int b, double const* u3 /* [
   double s = 0.;
   C8_UNROLL
   for (int n = 0; n < E::NN; ++n) s += Ap[n * sa] * Bp[n * sb];
-  return s;
-}
-template <class E, class SH> C8_HD double interp_q(SH const& sh, int pt, int c, bool prev) {
-  double s = 0.;
-  if (c < 9) {
-    int const i = c / 3, l = c - 3 * i;
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += (prev ? sh.u_prev[n][i] : sh.u[n][i]) * sh.dN[pt][n][l];
-  } else if (c == 9) {
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += sh.p[n] * sh.N[pt][n];
-  } else if (c < 13) {
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += sh.p[n] * sh.dN[pt][n][c - 10];
-  } else {
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += sh.u[n][c - 13] * sh.N[pt][n];
-  }
   return s;
 }
 
@@ -838,22 +820,6 @@ template <template <class> class ModelT> struct WaveLaneA {
   double dn[3], sx;        // cached shape tables: this lane's dN/dx entry; w dv (lanes 0..7) or h (lane 8)
 };
 
-// interpolate the adjoint nodal values like the point quantities (same B matrix)
-template <class E, class SH> C8_HD double interp_zq(SH const& sh, int pt, int c) {
-  double s = 0.;
-  if (c < 9) {
-    int const i = c / 3, l = c - 3 * i;
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += sh.z[3 * n + i] * sh.dN[pt][n][l];
-  } else if (c == 9) {
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += sh.z[3 * E::NN + n] * sh.N[pt][n];
-  } else if (c < 13) {
-    C8_UNROLL
-    for (int n = 0; n < E::NN; ++n) s += sh.z[3 * E::NN + n] * sh.dN[pt][n][c - 10];
-  }
-  return s;
-}
 
 // (d flux / ds) . (interpolated adjoint) for the tangent s carried by f: the point form of (dR/ds)^T z
 template <class SH> C8_HD double flux_dot_zq(SH const& sh, int pt, MechFlux<Dual> const& f) {
