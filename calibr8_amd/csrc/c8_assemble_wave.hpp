@@ -186,8 +186,75 @@ C8_HD double interp_ab(SH const& sh, int pt, int a, int b, double const* u3 /* [
   return s;
 }
 
-// Gauss-Jordan with row pivoting inside lane groups of G lanes: lane cg (< NL) of a group owns
-// column cg of the group's matrix Mg (in shared memory); see gj_solve in c8_assemble.hpp.
+// Gauss-Jordan with row pivoting inside lane groups of G lanes (see gj_solve in c8_assemble.hpp for the slot kernels).
+// Lane cg (< NL) of a group owns COLUMN cg of the group's matrix in its registers (col(lane, r), r = 0..NL-1) and every
+// lane of the group carries its own right-hand side b (registers).  Step s: the owner of column s publishes it through
+// the group's LDS matrix Mg (column s of Mg, one write and one read per entry: the only LDS traffic of a step), every
+// lane finds the same pivot row, swaps, eliminates its right-hand side and -- lanes cg > s -- its own column.  The
+// arithmetic is the one of an elimination on a shared matrix, entry by entry.
+template <int NL, int G, class EX, class GetM, class Col, class GetB, class Active>
+C8_HD bool gj_solve_cols(EX& ex, GetM getm, Col col, GetB getb, Active active) {
+  bool ok = true;
+  C8_UNROLL
+  for (int s = 0; s < NL; ++s) {
+    ex.each([&](int lane) {
+      if (!active(lane)) return;
+      if (lane % G == s) {
+        auto* M = getm(lane);  // double (*)[G + 1]
+        static_for<NL>([&](auto rc) { constexpr int r = decltype(rc)::value; M[r][s] = col(lane, r); });
+      }
+    });
+    ex.sync();
+    ex.each([&](int lane) {
+      if (!active(lane)) return;
+      int const cg = lane % G;
+      auto* M = getm(lane);
+      double* b = getb(lane);
+      double pc[NL];  // the pivot column
+      C8_UNROLL
+      for (int r = 0; r < NL; ++r) pc[r] = M[r][s];
+      int rstar = s;
+      double big = fabs(pc[s]);
+      C8_UNROLL
+      for (int r = s + 1; r < NL; ++r) {
+        double const a = fabs(pc[r]);
+        if (a > big) { big = a; rstar = r; }
+      }
+      if (!(big > 0.)) ok = false;
+      bool const mine = cg > s && cg < NL;  // this lane still has a column to eliminate
+      double const cs = pc[s], bs = b[s], ms = col(lane, s);
+      double cpiv = cs, bpiv = bs, mpiv = ms;
+      static_for<NL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        bool const hit = (r > s) && (r == rstar);
+        cpiv = hit ? pc[r] : cpiv;
+        bpiv = hit ? b[r] : bpiv;
+        mpiv = hit ? col(lane, r) : mpiv;
+        pc[r] = hit ? cs : pc[r];
+        b[r] = hit ? bs : b[r];
+        col(lane, r) = hit ? ms : col(lane, r);
+      });
+      double const inv = 1. / cpiv;
+      double const bsn = bpiv * inv;
+      b[s] = bsn;
+      C8_UNROLL
+      for (int r = 0; r < NL; ++r) if (r != s) b[r] -= pc[r] * bsn;
+      if (mine) {
+        double const msn = mpiv * inv;
+        static_for<NL>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if (r == s) col(lane, r) = msn;
+          else col(lane, r) -= pc[r] * msn;
+        });
+      }
+    });
+  }
+  return ok;
+}
+
+// The same elimination with the whole matrix in the group's LDS matrix Mg (lane cg updates column cg there): three
+// dependent LDS round trips per step instead of one, but no column held in registers -- for models whose local Newton
+// iteration has no registers to spare (Model::NEWTON_MATRIX_IN_LDS).
 template <int NL, int G, class EX, class GetM, class GetB, class Active>
 C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
   bool ok = true;
@@ -389,8 +456,15 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       });
       ex.sync();
       if (!ex.any(running)) break;
-      bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
-                                              [&](int lane) { return ex.lane(lane).b; }, running);
+      // column d of dC/dxi is this lane's own tangent: the elimination works on R[.].d in place
+      bool ok;
+      if constexpr (Model::NEWTON_MATRIX_IN_LDS)
+        ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                     [&](int lane) { return ex.lane(lane).b; }, running);
+      else
+        ok = gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                  [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; },
+                                  [&](int lane) { return ex.lane(lane).b; }, running);
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         if (!running(lane)) return;
@@ -433,11 +507,16 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         int const d = lane & 7;
+        int const pt = lane >> 3;
         C8_UNROLL
-        for (int j = 0; j < NL; ++j) r.b[j] = (j == d) ? 1. : 0.;
+        for (int j = 0; j < NL; ++j) {
+          r.b[j] = (j == d) ? 1. : 0.;
+          r.m.R[j].d = (d < NL) ? sh.M[pt][j][d] : 0.;  // this lane's column of dC/dxi
+        }
       });
-      bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
-                                              [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+      bool const ok = gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                           [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; },
+                                           [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         int const pt = lane >> 3, d = lane & 7;
@@ -941,12 +1020,16 @@ C8_HD void adjoint_local_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, Me
   ex.sync();
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
-    int const pt = lane >> 3;
+    int const pt = lane >> 3, d = lane & 7;
     C8_UNROLL
-    for (int j = 0; j < NL; ++j) r.b[j] = sh.vec[pt][j];
+    for (int j = 0; j < NL; ++j) {
+      r.b[j] = sh.vec[pt][j];
+      r.m.R[j].d = (d < NL) ? sh.M[pt][j][d] : 0.;  // this lane's column of (dC/dxi)^T
+    }
   });
-  bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
-                                          [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+  bool const ok = gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                       [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; },
+                                       [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
   // phi; xi_prev seeded: g = -(dC/dxi_prev)^T phi (:636-642); x_prev seeded through q_prev: w = (dC/dq_prev)^T phi
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);

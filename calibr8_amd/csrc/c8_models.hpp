@@ -60,6 +60,7 @@ template <class T> struct Elastic {
   // wave kernels: 256-thread workgroups per CU that the register budget is set for (2 -> 256 registers, 1 -> 512),
   // for the two Jacobian kernels and for the local-adjoint / parameter-gradient kernels
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
   C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
@@ -92,6 +93,7 @@ template <class T> struct IsotropicElastic {
   static constexpr int NLOC = 6, NPARAMS = 2;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
   C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
@@ -138,6 +140,7 @@ template <class T> struct SmallJ2 {
   static constexpr int NLOC = 7, NPARAMS = 6;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
   C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
@@ -197,6 +200,7 @@ template <class T> struct SmallHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
   C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
@@ -267,6 +271,7 @@ template <class T> struct HypoHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = true;  // K1 is slower with the matrix columns in registers (41.2 against 39.2 ms)
   T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (hypo_hill.cpp:84-95)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // TC(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }  // :123-131
@@ -364,6 +369,7 @@ template <class T> struct HyperJ2 {
   // measured on 1 M hex8 elements: at 256 registers the local-adjoint kernel spills 1 KB per lane (32 ms), at 512
   // registers and half the occupancy it takes 14.8 ms; the Jacobian kernels are faster at 2 workgroups per CU
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = true;  // K1 spills with the matrix columns in registers (32.5 against 28.8 ms)
   T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2.cpp:83-90)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // zeta(6), Ie, alpha
   C8_HD static void init_variables(double* xi0) {  // :119-134
