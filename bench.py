@@ -7,7 +7,9 @@ small_J2 (E 1000, nu 0.25, K 100, Y 2), prescribed mixed elastic/plastic state o
 For N > 1 the workload is weak-scaled: rank r owns one 100^3 block of a (px*100, py*100, pz*100) brick
 (2x2x2 blocks of an 8M-element brick at N = 8, BASELINE.json config 5).  A step is then the assembly
 plus the owned/ghost halo ADD of the Jacobian and residual (LinearAlg::gather_A/gather_b) over RCCL;
-`value` = all elements of all ranks / max-over-ranks wall time.
+`value` = all elements of all ranks / max-over-ranks wall time.  The exchange overlaps the assembly: in the
+default staged mode the ghost rows are summed first and travel while the owned rows are summed; with
+--scatter atomic the elements that add into ghost rows are assembled first.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
 Prints ONE JSON line on rank 0.
@@ -73,7 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--edge", dest="n", type=int, default=100, help="brick edge (elements) per GPU")
-    ap.add_argument("--scatter", default="atomic", choices=["colored", "atomic", "gather"])
+    ap.add_argument("--scatter", default="gather", choices=["colored", "atomic", "gather"],
+                    help="gather (default): staged assembly + row sums, no atomics, bitwise reproducible, fastest")
     ap.add_argument("--cpu-sample", type=int, default=32, help="edge of the CPU-baseline sample brick")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
@@ -127,15 +130,32 @@ def main():
     asm.set_async(True)
 
     overlap = world > 1 and args.scatter == "atomic" and not args.no_overlap
+    split = world > 1 and args.scatter == "gather" and not args.no_overlap
     if overlap:
         e_if = torch.as_tensor(plan.interface_elems, device=dev)
         e_in = torch.as_tensor(plan.interior_elems, device=dev)
+    if split:  # staged assembly in two parts: the ghost rows (local nodes nowned .. ntouched) are summed first
+        asm.set_gather_early_nodes(part.nowned, part.ntouched)
 
     def step(ev=None):
         """eval_forward_jacobian, then la->gather_A / gather_b (primal.cpp:99,110-111).  With more than one rank
         the elements that add into ghost rows are assembled first and the exchange of those rows (one grouped
         all_to_all) runs while the interior elements are assembled; `ev` = HIP-event pairs around the assembly
         launches."""
+        if split:  # every element staged, ghost rows summed; the other rows are summed while the ghost rows travel
+            if ev:
+                ev[0][0].record()
+            asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+            if ev:
+                ev[0][1].record()
+            h = halo.start_gather(ls)
+            if ev:
+                ev[1][0].record()
+            asm.gather_finish()
+            if ev:
+                ev[1][1].record()
+            halo.finish_gather(ls, h)
+            return
         if not overlap:
             if ev:
                 ev[0][0].record()
@@ -177,18 +197,20 @@ def main():
     dt = time.perf_counter() - t0
     assert asm.status() == 0
     # assembly kernels only (both launches of a step when the exchange is overlapped)
-    kernel_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in pairs[:2 if overlap else 1]) for pairs in ev]))
+    kernel_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in pairs[:2 if (overlap or split) else 1]) for pairs in ev]))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
     overlap_check = None
-    if overlap:  # untimed: the overlapped step against the blocking exchange after a whole assembly
+    if overlap or split:  # untimed: the overlapped step against the blocking exchange after a whole assembly
         ls.zero()
         step()
         ref_flat = ls.flat.clone()
         ls.zero()
+        if split:
+            asm.set_gather_early_nodes(0, 0)
         asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
         halo.finish_gather(ls, halo.start_gather(ls))
         no = part.nowned  # owned rows only: ghost rows are scratch after the exchange
@@ -226,6 +248,7 @@ def main():
                                   "by one grouped neighbour all_to_all (RCCL) per step",
                    "halo_send_bytes_per_step_max_rank": halo_bytes,
                    "halo_overlapped_with_interior_assembly": bool(overlap),
+                   "halo_overlapped_with_owned_row_sums": bool(split),
                    "overlap_vs_blocking_max_rel_diff": overlap_check},
     }
     if rank == 0:

@@ -150,6 +150,14 @@ class Assembler:
         m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC, "gather": _l.C8_SCATTER_GATHER}[mode]
         _l.check(self.L.c8_set_scatter_mode(self.h, m))
 
+    def set_gather_early_nodes(self, node_begin, node_end):
+        """scatter='gather' in two parts: Jacobian assemblies sum the rows of nodes [node_begin, node_end) only (the
+        ghost rows of a mesh part); gather_finish() sums the rest, e.g. while those rows are being exchanged."""
+        _l.check(self.L.c8_set_gather_early_nodes(self.h, int(node_begin), int(node_end)))
+
+    def gather_finish(self):
+        return self._rc(self.L.c8_gather_finish(self.h))
+
     def set_shape_cache(self, on):
         """cached shape tables of the hex8 wave kernels (default on; 1.7 KB per element)"""
         _l.check(self.L.c8_set_shape_cache(self.h, int(bool(on))))

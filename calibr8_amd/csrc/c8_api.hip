@@ -5,6 +5,7 @@
 // stream.  There is no CPU execution path here: without a HIP device c8_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -240,6 +241,24 @@ int c8_set_stage_chunk(c8_ctx* c, int min_chunk) {
   c->stage_min_chunk = min_chunk;
   return C8_OK;
 }
+int c8_set_gather_early_nodes(c8_ctx* c, int node_begin, int node_end) {
+  if (!c || node_begin < 0 || node_end < node_begin || node_end > c->mesh.nnodes) return fail(C8_ERR_ARG, "c8_set_gather_early_nodes: bad argument");
+  if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_gather_early_nodes: a staged assembly is waiting for c8_gather_finish");
+  C8_HIP(hipDeviceSynchronize());
+  stage_release(c);  // the node order is rebuilt at the next staged assembly
+  c->early_begin = node_begin;
+  c->early_end = node_end;
+  return C8_OK;
+}
+int c8_gather_finish(c8_ctx* c) {
+  if (!c) return fail(C8_ERR_ARG, "c8_gather_finish: null ctx");
+  if (!c->gather_pending) return C8_OK;
+  c->gather_pending = false;
+  int const total = (int)c->plan.node_order.size();
+  C8_HIP(c->ks.gather_rows(c->pending_ga, c->early_count, total - c->early_count, c->graph.max_degree, c->stream));
+  if (c->async) return C8_OK;
+  return c8_status(c);
+}
 int c8_set_kernel_variant(c8_ctx* c, int variant) {
   if (!c || variant < C8_KERNEL_AUTO || variant > C8_KERNEL_WAVE) return fail(C8_ERR_ARG, "c8_set_kernel_variant: bad argument");
   if (variant == C8_KERNEL_WAVE && !c->ks.forward_jacobian_wave)
@@ -289,6 +308,12 @@ static int stage_setup(c8_ctx* c) {
   if (min_chunk <= 0)
     min_chunk = ((double)c->mesh.nelems * c->ks.stage_stride * sizeof(double) <= 12e9) ? c->mesh.nelems : 262144;
   plan_staged_assembly(c->mesh, c->graph, min_chunk, min_chunk >= 256 ? 256 : 4, c->plan);
+  c->early_count = 0;
+  if (c->early_end > c->early_begin) {  // the early nodes' rows first (stable: both parts keep ascending node order)
+    if (c->plan.nchunks != 1) return fail(C8_ERR_UNSUPPORTED, "staged assembly in two parts needs the whole mesh in one staged chunk");
+    auto const early = [&](int32_t n) { return n >= c->early_begin && n < c->early_end; };
+    c->early_count = (int)(std::stable_partition(c->plan.node_order.begin(), c->plan.node_order.end(), early) - c->plan.node_order.begin());
+  }
   size_t const bytes = (size_t)c->plan.ring * c->ks.stage_stride * sizeof(double);
   if (hipMalloc((void**)&c->d_stage, bytes) != hipSuccess) return fail(C8_ERR_DEVICE, "staged assembly: cannot allocate the element stage");
   return upload(&c->d_node_order, c->plan.node_order);
@@ -311,6 +336,16 @@ static int run_staged(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs c
   sa.stage_ring = pl.ring;
   GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, c->d_stage, pl.ring, c->d_node_order,
                 {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
+  if (c->gather_pending) return fail(C8_ERR_ARG, "staged assembly: c8_gather_finish has not been called for the previous assembly");
+  if (c->early_end > c->early_begin) {  // two parts: the early rows now, the rest in c8_gather_finish
+    LaunchArgs a{tables(c, false), c->ms, fa, aa, sa, 0, c->mesh.nelems, c->stream};
+    C8_HIP(fn(a));
+    C8_HIP(c->ks.gather_rows(ga, 0, c->early_count, c->graph.max_degree, c->stream));
+    c->pending_ga = ga;
+    c->gather_pending = true;
+    if (c->async) return C8_OK;
+    return c8_status(c);
+  }
   for (int k = 0; k < pl.nchunks; ++k) {
     LaunchArgs a{tables(c, false), c->ms, fa, aa, sa, k * pl.chunk, std::min(pl.chunk, c->mesh.nelems - k * pl.chunk), c->stream};
     C8_HIP(fn(a));

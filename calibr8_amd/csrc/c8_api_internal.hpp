@@ -40,6 +40,11 @@ struct c8_ctx {
   int32_t* d_node_order = nullptr;
   c8::StagePlan plan;                 // staged assembly: chunks, ring, node order
   int stage_min_chunk = 0;            // 0: automatic (c8_api.hip: stage_setup)
+  // staged assembly in two parts (c8_set_gather_early_nodes): the rows of nodes [early_begin, early_end) are summed by
+  // the assembly call, the other rows by c8_gather_finish
+  int early_begin = 0, early_end = 0, early_count = 0;
+  bool gather_pending = false;
+  c8::GatherArgs pending_ga{};
   double* d_shape = nullptr;          // cached shape tables of the wave kernels, [nelems][ks.shape_stride] (hex8; null: computed per call)
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}

@@ -120,6 +120,14 @@ int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_COLORED (default),
  * smaller than the element bandwidth of the mesh) through a ring of three chunks.  Default: the whole mesh in one
  * chunk while its stage stays under 12 GB (8.4 KB per hex8, 2.2 KB per tet4 element), else chunks of 262144. */
 int c8_set_stage_chunk(c8_ctx* ctx, int min_chunk);
+/* C8_SCATTER_GATHER in two parts, for a caller that exchanges ghost rows (LinearAlg::gather_A / gather_b,
+ * linear_alg.cpp:53-86): with an early node range set, a Jacobian assembly stages every element and sums the rows of
+ * the nodes [node_begin, node_end) only -- the ghost rows, which the caller can then pack and send -- and
+ * c8_gather_finish sums the rows of all other nodes while the exchange is in flight.  Every assembly must then be
+ * followed by c8_gather_finish before the system is used.  Needs the whole mesh in one staged chunk; an empty range
+ * (the default) turns the split off. */
+int c8_set_gather_early_nodes(c8_ctx* ctx, int node_begin, int node_end);
+int c8_gather_finish(c8_ctx* ctx);
 /* Shape-table cache (default on; hex8 wave kernels): the geometry of a context is static, so dN/dx, w dv and the element
  * size are computed once at c8_create (1.7 KB per element) instead of by every call (weight.cpp:5-25 recomputes them for
  * every AD pass).  on = 0 frees the tables; results are the same either way. */

@@ -156,6 +156,39 @@ def test_wave_kernels_without_shape_cache(model, params, eps):
     check_forward(orc, gpu, c, model, eps, TOL)
 
 
+def test_staged_gather_in_two_parts():
+    # c8_set_gather_early_nodes: the assembly call sums the rows of an early node range only (the ghost rows of a mesh
+    # part), c8_gather_finish the rest; the result is bitwise the one of the single-call staged assembly
+    import torch
+    from calibr8_amd import Assembler
+    c, conn = hex_mesh((6, 5, 4))
+    asm = Assembler(8, c, conn, "small_J2", J2, scatter="gather")
+    u_h, p_h = prescribed_fields(c, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    xi0 = asm.new_state()
+    ref, xi_ref = asm.new_linsys(), asm.new_state()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, xi_ref, ref) == 0
+    nn = len(c)
+    for lo, hi in ((nn // 3, nn // 2), (0, nn), (nn - 1, nn)):
+        asm.set_gather_early_nodes(lo, hi)
+        ls, xi = asm.new_linsys(), asm.new_state()
+        assert asm.forward_jacobian(u, p, z, zp, xi0, xi, ls) == 0
+        # after the first part exactly the early rows are complete
+        r3 = asm.rowptr[0][0]
+        a, b = int(r3[3 * lo]), int(r3[3 * hi])
+        assert torch.equal(ls.A[0][0][a:b], ref.A[0][0][a:b]) and torch.equal(ls.b[0][3 * lo:3 * hi], ref.b[0][3 * lo:3 * hi])
+        if hi - lo < nn:
+            assert not torch.equal(ls.flat, ref.flat)
+            with pytest.raises(RuntimeError, match="c8_gather_finish"):
+                asm.forward_jacobian(u, p, z, zp, xi0, xi, ls)
+        assert asm.gather_finish() == 0
+        assert torch.equal(ls.flat, ref.flat) and torch.equal(xi, xi_ref)
+    asm.set_gather_early_nodes(0, 0)
+    ls = asm.new_linsys()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, asm.new_state(), ls) == 0 and torch.equal(ls.flat, ref.flat)
+
+
 def test_staged_gather_slot_kernel_hex8():
     orc, gpu, c = make_pair(factory("gather", "slot"), "hex8", "small_J2", J2)
     check_forward(orc, gpu, c, "small_J2", 0.004, TOL)

@@ -4,20 +4,23 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-batch}
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_atomic -- python3 bench.py --no-cpu > $O/prof_atomic.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_atomic -- python3 bench.py --no-cpu --scatter atomic > $O/prof_atomic.log 2>&1 || exit 1
 echo prof_atomic done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gather -- python3 bench.py --no-cpu --scatter gather > $O/prof_gather.log 2>&1 || exit 1
 echo prof_gather done
 timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo bench default done
-timeout -k 10 200 python3 bench.py --no-cpu --scatter gather > $O/bench_gather.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu --scatter atomic > $O/bench_atomic.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scatter colored > $O/bench_colored.json 2>/dev/null || exit 1
 echo bench modes done
 timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_atomic.json -- --scatter atomic > $O/pmc_atomic.log 2>&1 || exit 1
+timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_gather.json -- --scatter gather > $O/pmc_gather.log 2>&1 || exit 1
 echo pmc done
 timeout -k 10 300 python3 tools/bench_kernels.py > $O/kernels_small_J2.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model hyper_J2 > $O/kernels_hyper_J2.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model small_hill > $O/kernels_small_hill.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/bench_kernels.py --model hypo_hill > $O/kernels_hypo_hill.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/bench_kernels.py --scatter gather > $O/kernels_small_J2_gather.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --tet --edge 56 --scatter gather > $O/kernels_tet4_gather.json 2>/dev/null || exit 1
 echo kernels done
 timeout -k 10 400 python3 tools/bench_fractions.py > $O/fractions.json 2>/dev/null || exit 1
