@@ -20,7 +20,6 @@ timeout -k 10 300 python3 tools/bench_kernels.py > $O/kernels_small_J2.json 2>/d
 timeout -k 10 300 python3 tools/bench_kernels.py --model hyper_J2 > $O/kernels_hyper_J2.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model small_hill > $O/kernels_small_hill.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model hypo_hill > $O/kernels_hypo_hill.json 2>/dev/null || exit 1
-timeout -k 10 300 python3 tools/bench_kernels.py --scatter gather > $O/kernels_small_J2_gather.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --tet --edge 56 --scatter gather > $O/kernels_tet4_gather.json 2>/dev/null || exit 1
 echo kernels done
 timeout -k 10 400 python3 tools/bench_fractions.py > $O/fractions.json 2>/dev/null || exit 1
