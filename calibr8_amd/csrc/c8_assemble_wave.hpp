@@ -252,6 +252,70 @@ C8_HD bool gj_solve_cols(EX& ex, GetM getm, Col col, GetB getb, Active active) {
   return ok;
 }
 
+// The same elimination with the pivot column handed over by a cross-lane broadcast (ex.bcast8: DPP moves on the GPU) --
+// no LDS traffic and no barrier in a step, but six VALU operations per value.  Which hand-over is faster depends on the
+// registers the surrounding code leaves free: a per-model, per-kernel trait (GJ_XLANE_JAC, GJ_XLANE_K4), as measured.
+template <int NL, class EX, class Col, class GetB, class Active>
+C8_HD bool gj_solve_xlane(EX& ex, Col col, GetB getb, Active active) {
+  bool ok = true;
+  static_for<NL>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    ex.each([&](int lane) {
+      if (!active(lane)) return;
+      int const cg = lane & 7;
+      double* b = getb(lane);
+      double pc[NL];  // the pivot column
+      static_for<NL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        pc[r] = ex.template bcast8<s>(lane, [&](int l) -> double { return col(l, r); });
+      });
+      int rstar = s;
+      double big = fabs(pc[s]);
+      C8_UNROLL
+      for (int r = s + 1; r < NL; ++r) {
+        double const a = fabs(pc[r]);
+        if (a > big) { big = a; rstar = r; }
+      }
+      if (!(big > 0.)) ok = false;
+      bool const mine = cg > s && cg < NL;  // this lane still has a column to eliminate
+      double const cs = pc[s], bs = b[s], ms = col(lane, s);
+      double cpiv = cs, bpiv = bs, mpiv = ms;
+      static_for<NL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        bool const hit = (r > s) && (r == rstar);
+        cpiv = hit ? pc[r] : cpiv;
+        bpiv = hit ? b[r] : bpiv;
+        mpiv = hit ? col(lane, r) : mpiv;
+        pc[r] = hit ? cs : pc[r];
+        b[r] = hit ? bs : b[r];
+        col(lane, r) = (hit && mine) ? ms : col(lane, r);  // the owner of the pivot column leaves it as broadcast
+      });
+      double const inv = 1. / cpiv;
+      double const bsn = bpiv * inv;
+      b[s] = bsn;
+      C8_UNROLL
+      for (int r = 0; r < NL; ++r) if (r != s) b[r] -= pc[r] * bsn;
+      if (mine) {
+        double const msn = mpiv * inv;
+        static_for<NL>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if (r == s) col(lane, r) = msn;
+          else col(lane, r) -= pc[r] * msn;
+        });
+      }
+    });
+  });
+  return ok;
+}
+
+// the local solve of the wave kernels: column d of the matrix is lane d's R[.].d, the right-hand side is lane.b
+template <int NL, bool XLANE, class EX, class SH, class Active> C8_HD bool local_solve(EX& ex, SH& sh, Active active) {
+  auto col = [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; };
+  auto rhs = [&](int lane) { return ex.lane(lane).b; };
+  if constexpr (XLANE) return gj_solve_xlane<NL>(ex, col, rhs, active);
+  else return gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; }, col, rhs, active);
+}
+
 // The same elimination with the whole matrix in the group's LDS matrix Mg (lane cg updates column cg there): three
 // dependent LDS round trips per step instead of one, but no column held in registers -- for models whose local Newton
 // iteration has no registers to spare (Model::NEWTON_MATRIX_IN_LDS).
@@ -462,9 +526,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
         ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
                                      [&](int lane) { return ex.lane(lane).b; }, running);
       else
-        ok = gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
-                                  [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; },
-                                  [&](int lane) { return ex.lane(lane).b; }, running);
+        ok = local_solve<NL, Model::GJ_XLANE_JAC>(ex, sh, running);
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         if (!running(lane)) return;
@@ -514,9 +576,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
           r.m.R[j].d = (d < NL) ? sh.M[pt][j][d] : 0.;  // this lane's column of dC/dxi
         }
       });
-      bool const ok = gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
-                                           [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; },
-                                           [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+      bool const ok = local_solve<NL, Model::GJ_XLANE_JAC>(ex, sh, [](int) { return true; });
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         int const pt = lane >> 3, d = lane & 7;
@@ -1027,9 +1087,7 @@ C8_HD void adjoint_local_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, Me
       r.m.R[j].d = (d < NL) ? sh.M[pt][j][d] : 0.;  // this lane's column of (dC/dxi)^T
     }
   });
-  bool const ok = gj_solve_cols<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
-                                       [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; },
-                                       [&](int lane) { return ex.lane(lane).b; }, [](int) { return true; });
+  bool const ok = local_solve<NL, Model::GJ_XLANE_K4>(ex, sh, [](int) { return true; });
   // phi; xi_prev seeded: g = -(dC/dxi_prev)^T phi (:636-642); x_prev seeded through q_prev: w = (dC/dq_prev)^T phi
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);

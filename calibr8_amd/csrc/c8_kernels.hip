@@ -45,6 +45,20 @@ template <class Lane> struct GpuExec {
     else *p += v;
   }
   __device__ __forceinline__ void flag(int* s) { atomicOr(s, 1); }
+  // get(l) evaluated in lane S of the caller's group of 8 lanes (lanes 8g .. 8g+7), returned to every lane of the
+  // group: two DPP row broadcasts (lane S and lane 8+S of each row of 16) and a select per 32-bit half, no LDS and no
+  // barrier.  The source lane must be active whenever a reader is (a group is active or inactive as a whole wherever
+  // this is used).  (ds_bpermute_b32 instead of DPP: measured slower on every model.)
+  template <int S, class F> __device__ __forceinline__ double bcast8(int lane, F get) {
+    double const x = get(lane);
+    int const lo = __double2loint(x), hi = __double2hiint(x);
+    int const a_lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + S, 0xf, 0xf, false);  // row_newbcast:S
+    int const a_hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + S, 0xf, 0xf, false);
+    int const b_lo = __builtin_amdgcn_update_dpp(0, lo, 0x158 + S, 0xf, 0xf, false);  // row_newbcast:8+S
+    int const b_hi = __builtin_amdgcn_update_dpp(0, hi, 0x158 + S, 0xf, 0xf, false);
+    bool const upper = (k & 8) != 0;
+    return __hiloint2double(upper ? b_hi : a_hi, upper ? b_lo : a_lo);
+  }
 #ifdef C8_STAMPS
   // element e is sampled when e % 244 == 0 (4096 samples over a 1M-element mesh)
   __device__ __forceinline__ void stamp(SystemArgs const& sa, int e, int i) {
@@ -170,7 +184,7 @@ static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
 #ifdef C8_EXPERIMENT_K4_WAVES  // timing experiment: waves per SIMD of the local-adjoint kernel, every model
 #define C8_K4_WAVES(M) C8_EXPERIMENT_K4_WAVES
 #else
-#define C8_K4_WAVES(M) M::WAVE_BLOCKS_PER_CU_ADJ
+#define C8_K4_WAVES(M) M::WAVE_BLOCKS_PER_CU_K4
 #endif
 template <class E, template <class> class ModelT>
 __global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(C8_K4_WAVES(ModelT<Dual>), C8_K4_WAVES(ModelT<Dual>))))

@@ -60,6 +60,8 @@ template <class T> struct Elastic {
   // wave kernels: 256-thread workgroups per CU that the register budget is set for (2 -> 256 registers, 1 -> 512),
   // for the two Jacobian kernels and for the local-adjoint / parameter-gradient kernels
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;  // waves per SIMD of the local-adjoint wave kernel
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
@@ -93,6 +95,8 @@ template <class T> struct IsotropicElastic {
   static constexpr int NLOC = 6, NPARAMS = 2;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;  // waves per SIMD of the local-adjoint wave kernel
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
@@ -140,6 +144,8 @@ template <class T> struct SmallJ2 {
   static constexpr int NLOC = 7, NPARAMS = 6;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 3;  // 162 registers: three waves per SIMD (3.1 against 3.5 ms per million elements)
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = true;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
@@ -200,6 +206,8 @@ template <class T> struct SmallHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;  // waves per SIMD of the local-adjoint wave kernel
+  static constexpr bool GJ_XLANE_JAC = true, GJ_XLANE_K4 = true;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
@@ -271,6 +279,8 @@ template <class T> struct HypoHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;  // waves per SIMD of the local-adjoint wave kernel
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
   static constexpr bool NEWTON_MATRIX_IN_LDS = true;  // K1 is slower with the matrix columns in registers (41.2 against 39.2 ms)
   T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (hypo_hill.cpp:84-95)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // TC(00,01,02,11,12,22), alpha
@@ -369,6 +379,8 @@ template <class T> struct HyperJ2 {
   // measured on 1 M hex8 elements: at 256 registers the local-adjoint kernel spills 1 KB per lane (32 ms), at 512
   // registers and half the occupancy it takes 14.8 ms; the Jacobian kernels are faster at 2 workgroups per CU
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;  // waves per SIMD of the local-adjoint wave kernel
+  static constexpr bool GJ_XLANE_JAC = true, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
   static constexpr bool NEWTON_MATRIX_IN_LDS = true;  // K1 spills with the matrix columns in registers (32.5 against 28.8 ms)
   T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2.cpp:83-90)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // zeta(6), Ie, alpha

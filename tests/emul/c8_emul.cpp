@@ -34,6 +34,17 @@ template <class Lane, int NDOF> struct CpuExec {
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
   void flag(int* s) { *s = 1; }
+  // the value of get() in lane S of the caller's group of 8 lanes (GpuExec: DPP broadcast).  Sound in this serial
+  // emulation only where lane S does not change the value during the same each(): true for the pivot column of an
+  // elimination step, which its owner leaves alone in that step.
+  template <int S, class F> double bcast8(int lane, F get) {
+    int const saved = cur;
+    int const src = (lane & ~7) + S;
+    cur = src;
+    double const v = get(src);
+    cur = saved;
+    return v;
+  }
 };
 
 enum { K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
