@@ -888,7 +888,7 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
     for (int it = 0; it < GL::N00; ++it) {
       int const j = lane + 64 * it;
       if (j < 9 * deg) {
-        int const i = j / n3, jj = j - i * n3, pos = jj / 3, col = jj - 3 * pos;
+        int const i = (j >= n3) + (j >= 2 * n3), jj = j - i * n3, pos = jj / 3, col = jj - 3 * pos;  // i = j / n3 < 3
         ga.A[0][0][np * 9 + j] = r.a00[it] + sh.acc[pos][i * 4 + col];
       }
     }
@@ -896,7 +896,7 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
     for (int it = 0; it < GL::N01; ++it) {
       int const j = lane + 64 * it;
       if (j < n3) {
-        int const i = j / deg, pos = j - i * deg;          // block (0,1): rows u_i, deg entries each
+        int const i = (j >= deg) + (j >= 2 * deg), pos = j - i * deg;  // block (0,1): rows u_i = j / deg < 3, deg entries each
         ga.A[0][1][np * 3 + j] = r.a01[it] + sh.acc[pos][i * 4 + 3];
         int const pos2 = j / 3, col = j - 3 * pos2;        // block (1,0): the p row, 3*deg entries
         ga.A[1][0][np * 3 + j] = r.a10[it] + sh.acc[pos2][3 * 4 + col];

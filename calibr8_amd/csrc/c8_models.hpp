@@ -280,8 +280,8 @@ template <class T> struct HypoHill {
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
   static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;  // waves per SIMD of the local-adjoint wave kernel
-  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
-  static constexpr bool NEWTON_MATRIX_IN_LDS = true;  // K1 is slower with the matrix columns in registers (41.2 against 39.2 ms)
+  static constexpr bool GJ_XLANE_JAC = true, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // with the DPP hand-over K1 takes 32.5 ms (39.2 with the matrix in LDS)
   T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (hypo_hill.cpp:84-95)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // TC(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }  // :123-131
