@@ -308,6 +308,13 @@ C8_HD bool gj_solve_xlane(EX& ex, Col col, GetB getb, Active active) {
   return ok;
 }
 
+#ifdef C8_EXPERIMENT_XL  // timing experiment: hand-over of the Newton solve (bit 0) and of the inverse (bit 1), every model
+#define C8_XL_NEWTON(M) ((C8_EXPERIMENT_XL & 1) != 0)
+#define C8_XL_INVERSE(M) ((C8_EXPERIMENT_XL & 2) != 0)
+#else
+#define C8_XL_NEWTON(M) M::GJ_XLANE_JAC
+#define C8_XL_INVERSE(M) M::GJ_XLANE_JAC
+#endif
 // the local solve of the wave kernels: column d of the matrix is lane d's R[.].d, the right-hand side is lane.b
 template <int NL, bool XLANE, class EX, class SH, class Active> C8_HD bool local_solve(EX& ex, SH& sh, Active active) {
   auto col = [&](int lane, int j) -> double& { return ex.lane(lane).m.R[j].d; };
@@ -526,7 +533,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
         ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
                                      [&](int lane) { return ex.lane(lane).b; }, running);
       else
-        ok = local_solve<NL, Model::GJ_XLANE_JAC>(ex, sh, running);
+        ok = local_solve<NL, C8_XL_NEWTON(Model)>(ex, sh, running);
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         if (!running(lane)) return;
@@ -576,7 +583,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
           r.m.R[j].d = (d < NL) ? sh.M[pt][j][d] : 0.;  // this lane's column of dC/dxi
         }
       });
-      bool const ok = local_solve<NL, Model::GJ_XLANE_JAC>(ex, sh, [](int) { return true; });
+      bool const ok = local_solve<NL, C8_XL_INVERSE(Model)>(ex, sh, [](int) { return true; });
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         int const pt = lane >> 3, d = lane & 7;
