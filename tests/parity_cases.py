@@ -107,7 +107,9 @@ def check_adjoint_chain(orc, dut, c, model, eps, tol):
         # K5
         gr_o = orc.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
         gr_d = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
-        scale = np.maximum(np.abs(gr_o), 1e-300)
+        # per component, relative; a component that is a cancelled sum (1e-6 of the largest one or less: seed 1598 of the
+        # sweep has dJ/dE = 6e-12 beside 4e-4) is measured against that floor instead of against itself
+        scale = np.maximum(np.abs(gr_o), 1e-6 * np.abs(gr_o).max() + 1e-300)
         assert (np.abs(gr_d - gr_o) / scale).max() < 1e-11, ("qoi_gradient", n, gr_d, gr_o)
         # K6
         assert abs(dut.eval_qoi(u, p) - orc.eval_qoi(u, p)) < tol * max(1.0, abs(orc.eval_qoi(u, p)))
