@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
     ap.add_argument("--stage-chunk", type=int, default=0, help="scatter=gather: minimum elements per staged chunk")
+    ap.add_argument("--assign", action="store_true", help="scatter=gather: c8_set_assign_mode (zero_all + assembly in one call); "
+                    "NOT the default: the contract metric is the accumulate-into assembly")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the ghost rows after the whole assembly")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -134,6 +136,8 @@ def main():
     if overlap:
         e_if = torch.as_tensor(plan.interface_elems, device=dev)
         e_in = torch.as_tensor(plan.interior_elems, device=dev)
+    if args.assign:
+        asm.set_assign_mode(True)
     if split:  # staged assembly in two parts: the ghost rows (local nodes nowned .. ntouched) are summed first
         asm.set_gather_early_nodes(part.nowned, part.ntouched)
 
@@ -248,7 +252,7 @@ def main():
                                   "by one grouped neighbour all_to_all (RCCL) per step",
                    "halo_send_bytes_per_step_max_rank": halo_bytes,
                    "halo_overlapped_with_interior_assembly": bool(overlap),
-                   "halo_overlapped_with_owned_row_sums": bool(split),
+                   "halo_overlapped_with_owned_row_sums": bool(split), "assign_mode": bool(args.assign),
                    "overlap_vs_blocking_max_rel_diff": overlap_check},
     }
     if rank == 0:

@@ -150,6 +150,10 @@ class Assembler:
         m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC, "gather": _l.C8_SCATTER_GATHER}[mode]
         _l.check(self.L.c8_set_scatter_mode(self.h, m))
 
+    def set_assign_mode(self, on):
+        """scatter='gather': Jacobian assemblies assign A and b (zero_all + assembly in one call) instead of adding"""
+        _l.check(self.L.c8_set_assign_mode(self.h, int(bool(on))))
+
     def set_gather_early_nodes(self, node_begin, node_end):
         """scatter='gather' in two parts: Jacobian assemblies sum the rows of nodes [node_begin, node_end) only (the
         ghost rows of a mesh part); gather_finish() sums the rest, e.g. while those rows are being exchanged."""

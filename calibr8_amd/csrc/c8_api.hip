@@ -241,6 +241,12 @@ int c8_set_stage_chunk(c8_ctx* c, int min_chunk) {
   c->stage_min_chunk = min_chunk;
   return C8_OK;
 }
+int c8_set_assign_mode(c8_ctx* c, int on) {
+  if (!c) return fail(C8_ERR_ARG, "c8_set_assign_mode: null ctx");
+  if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_assign_mode: a staged assembly is waiting for c8_gather_finish");
+  c->assign_mode = on ? 1 : 0;
+  return C8_OK;
+}
 int c8_set_gather_early_nodes(c8_ctx* c, int node_begin, int node_end) {
   if (!c || node_begin < 0 || node_end < node_begin || node_end > c->mesh.nnodes) return fail(C8_ERR_ARG, "c8_set_gather_early_nodes: bad argument");
   if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_gather_early_nodes: a staged assembly is waiting for c8_gather_finish");
@@ -335,7 +341,7 @@ static int run_staged(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs c
   sa.stage = c->d_stage;
   sa.stage_ring = pl.ring;
   GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, c->d_stage, pl.ring, c->d_node_order,
-                {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
+                {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}, c->assign_mode};
   if (c->gather_pending) return fail(C8_ERR_ARG, "staged assembly: c8_gather_finish has not been called for the previous assembly");
   if (c->early_end > c->early_begin) {  // two parts: the early rows now, the rest in c8_gather_finish
     LaunchArgs a{tables(c, false), c->ms, fa, aa, sa, 0, c->mesh.nelems, c->stream};
@@ -375,6 +381,8 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
                        (fn == c->ks.adjoint_jacobian && c->ks.adjoint_slot_stages));
   if (scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !staged)
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly of hex8 adjoint Jacobians needs the wave-per-element kernel");
+  if (c->assign_mode && scatters && sa.A[0][0] && !staged)
+    return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": assign mode (c8_set_assign_mode) needs the staged Jacobian assembly (C8_SCATTER_GATHER)");
   if (staged) return run_staged(c, fn, fa, aa, sa);
   LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
   if (c->subset) {
@@ -452,6 +460,10 @@ int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const
       if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null A block");
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
+  // the face term of the calibration objective is added to b after the row sums: with assign mode AND the row sums in
+  // two parts, the second part would overwrite it
+  if (c->assign_mode && c->qoi_kind == 1 && c->early_end > c->early_begin && c->scatter_mode == C8_SCATTER_GATHER)
+    return fail(C8_ERR_UNSUPPORTED, "c8_assemble_adjoint_jacobian: assign mode with two-part row sums and the calibration objective");
   int rc = c8_qoi_prepare(c, field_args(st));  // preprocess_qoi (evaluations.cpp:365)
   if (rc) return rc;
   AdjointArgs aa{g, const_cast<double*>(f), nullptr, nullptr, nullptr, nullptr, c->d_active, c8_qoi_args(c)};

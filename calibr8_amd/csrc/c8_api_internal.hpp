@@ -65,6 +65,7 @@ struct c8_ctx {
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
   int kernel_variant = C8_KERNEL_AUTO;
+  int assign_mode = 0;               // staged Jacobian assemblies assign their outputs instead of adding to them
   int async = 0;
   int32_t const* subset = nullptr;   // set for the duration of a *_subset call
   int subset_count = 0;

@@ -95,6 +95,7 @@ struct GatherArgs {
   int32_t const* node_order;    // nodes to process (StagePlan::node_order)
   double* A[2][2];
   double* b[2];
+  int assign = 0;               // 1: the rows are assigned (A = sum, b = sum) instead of added to (c8_set_assign_mode)
 };
 // stage[e]: for every element node n the four rows (u_0, u_1, u_2, p) of that node, NDOF columns each, in element
 // DOF order -- the 4*NDOF values a node's row sum needs from this element are contiguous -- then the NDOF entries of

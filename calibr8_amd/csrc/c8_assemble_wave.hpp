@@ -826,17 +826,21 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
     // the CSR entries this lane will update: loaded now, so that their round trip overlaps the stage loads.
     // Block (0,0): the node's three u rows are contiguous (3*deg entries each), one run of 9*deg values;
     // blocks (0,1) and (1,0): runs of 3*deg values; block (1,1): deg values.
+    // (assign mode: nothing to read, the rows start from zero -- uniform over the launch)
     C8_UNROLL
     for (int it = 0; it < GL::N00; ++it) {
       int const j = lane + 64 * it;
-      if (j < 9 * deg) r.a00[it] = ga.A[0][0][np * 9 + j];
+      r.a00[it] = 0.;
+      if (!ga.assign && j < 9 * deg) r.a00[it] = ga.A[0][0][np * 9 + j];
     }
     C8_UNROLL
     for (int it = 0; it < GL::N01; ++it) {
       int const j = lane + 64 * it;
-      if (j < n3) { r.a01[it] = ga.A[0][1][np * 3 + j]; r.a10[it] = ga.A[1][0][np * 3 + j]; }
+      r.a01[it] = r.a10[it] = 0.;
+      if (!ga.assign && j < n3) { r.a01[it] = ga.A[0][1][np * 3 + j]; r.a10[it] = ga.A[1][0][np * 3 + j]; }
     }
-    if (lane < deg) r.a11 = ga.A[1][1][np + lane];
+    r.a11 = 0.;
+    if (!ga.assign && lane < deg) r.a11 = ga.A[1][1][np + lane];
     C8_UNROLL
     for (int it = 0; it < MAXDEG / 4; ++it) {
       int const q = lane + 64 * it;
@@ -910,8 +914,8 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
       }
     }
     if (lane < deg) ga.A[1][1][np + lane] = r.a11 + sh.acc[lane][15];
-    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] += r.rsum;
-    if (lane == 3) ga.b[1][node] += r.rsum;
+    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] = (ga.assign ? 0. : ga.b[0][(size_t)node * 3 + lane]) + r.rsum;
+    if (lane == 3) ga.b[1][node] = (ga.assign ? 0. : ga.b[1][node]) + r.rsum;
   });
   ex.sync();
 }

@@ -189,6 +189,45 @@ def test_staged_gather_in_two_parts():
     assert asm.forward_jacobian(u, p, z, zp, xi0, asm.new_state(), ls) == 0 and torch.equal(ls.flat, ref.flat)
 
 
+def test_staged_gather_assign_mode():
+    # c8_set_assign_mode: zero_all + assembly in one call.  On any initial content of A and b the result is bitwise the
+    # accumulate-into result on a zeroed system (every node of this mesh has elements); a Jacobian assembly in another
+    # scatter mode is refused while the mode is on.
+    import torch
+    from calibr8_amd import Assembler
+    c, conn = hex_mesh((5, 4, 4))
+    asm = Assembler(8, c, conn, "small_J2", J2, scatter="gather")
+    u_h, p_h = prescribed_fields(c, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    xi0 = asm.new_state()
+    ref, xi_ref = asm.new_linsys(), asm.new_state()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, xi_ref, ref) == 0
+    asm.set_assign_mode(True)
+    ls = asm.new_linsys()
+    ls.flat.fill_(123.456)  # stale content
+    assert asm.forward_jacobian(u, p, z, zp, xi0, asm.new_state(), ls) == 0
+    assert torch.equal(ls.flat, ref.flat)
+    assert asm.forward_jacobian(u, p, z, zp, xi0, asm.new_state(), ls) == 0  # again: assigned, not doubled
+    assert torch.equal(ls.flat, ref.flat)
+    # K3 too
+    g = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=asm.device)
+    f = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=asm.device)
+    ls.flat.fill_(-7.0)
+    asm.adjoint_jacobian(u, p, z, zp, xi0, xi_ref, g, f, ls)
+    asm.set_assign_mode(False)
+    ref3 = asm.new_linsys()
+    asm.adjoint_jacobian(u, p, z, zp, xi0, xi_ref, torch.zeros_like(g), f, ref3)
+    assert torch.equal(ls.flat, ref3.flat)
+    asm.set_assign_mode(True)
+    b_before = ls.b[0].clone()
+    asm.global_residual(u, p, z, zp, xi0, xi_ref, ls)  # the residual-only assembly keeps adding
+    assert not torch.equal(ls.b[0], b_before)
+    asm.set_scatter("atomic")
+    with pytest.raises(RuntimeError, match="assign mode"):
+        asm.forward_jacobian(u, p, z, zp, xi0, asm.new_state(), ls)
+
+
 def test_staged_gather_slot_kernel_hex8():
     orc, gpu, c = make_pair(factory("gather", "slot"), "hex8", "small_J2", J2)
     check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
