@@ -126,6 +126,8 @@ int c8_set_stage_chunk(c8_ctx* ctx, int min_chunk);
  * c8_gather_finish sums the rows of all other nodes while the exchange is in flight.  Every assembly must then be
  * followed by c8_gather_finish before the system is used.  Needs the whole mesh in one staged chunk; an empty range
  * (the default) turns the split off. */
+int c8_set_gather_early_nodes(c8_ctx* ctx, int node_begin, int node_end);
+int c8_gather_finish(c8_ctx* ctx);
 /* C8_SCATTER_GATHER, assign mode (default off = the reference's accumulate-into semantics): the two Jacobian assemblies
  * ASSIGN the rows of A (all four blocks) and b of every node that has elements instead of adding to them, i.e.
  * la->zero_all() followed by eval_forward_jacobian / eval_adjoint_jacobian (primal.cpp:98-99, adjoint.cpp:123-125) in one
@@ -133,8 +135,6 @@ int c8_set_stage_chunk(c8_ctx* ctx, int min_chunk);
  * both go away.  Rows of nodes without elements are not touched.  The other entry points (residual-only assembly,
  * boundary conditions, ...) keep adding; a Jacobian assembly in another scatter mode is refused while the mode is on. */
 int c8_set_assign_mode(c8_ctx* ctx, int on);
-int c8_set_gather_early_nodes(c8_ctx* ctx, int node_begin, int node_end);
-int c8_gather_finish(c8_ctx* ctx);
 /* Shape-table cache (default on; hex8 wave kernels): the geometry of a context is static, so dN/dx, w dv and the element
  * size are computed once at c8_create (1.7 KB per element) instead of by every call (weight.cpp:5-25 recomputes them for
  * every AD pass).  on = 0 frees the tables; results are the same either way. */
