@@ -84,6 +84,7 @@ extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
 struct Call {
   int what;
   int staged;  // wave Jacobian kernels: staged (gather) assembly instead of direct adds
+  int assign;  // staged assembly: the row sums assign A and b instead of adding (c8_set_assign_mode)
   int nnodes;
   HostGraph const* graph;
   HostMesh const* mesh;
@@ -108,7 +109,7 @@ template <class E, class Assemble> static void run_staged(Call const& c, Assembl
   auto* gsh = new GatherShared<E, GATHER_MAX_DEGREE>();
   auto* gex = new CpuExec<GatherLane<E, GATHER_MAX_DEGREE>, 64>();
   GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), stage.data(), pl.ring,
-                pl.node_order.data(), {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}};
+                pl.node_order.data(), {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}, c.assign};
   for (int k = 0; k < pl.nchunks; ++k) {
     int const e1 = std::min(c.nelems, (k + 1) * pl.chunk);
     for (int e = k * pl.chunk; e < e1; ++e) assemble(sa, e);
@@ -285,6 +286,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   Call c;
   c.what = what & 0xff;
   c.staged = (what >> 8) & 1;
+  c.assign = (what >> 9) & 1;
   c.nnodes = nnodes;
   c.graph = &graph;
   c.mesh = &mesh;

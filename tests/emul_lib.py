@@ -47,6 +47,7 @@ class Emul:
         self.set_active(0, [0])
         self.wave = False  # True: K1 through the wave-per-element kernel (hex8 only)
         self.staged = False  # staged (gather) assembly of the two Jacobian kernels (hex8 slot K3 excepted)
+        self.assign = False  # staged assembly: assign A and b instead of adding (c8_set_assign_mode)
 
     def new_state(self):
         return self.orc.new_state()
@@ -86,14 +87,14 @@ class Emul:
         return {6: ls.A[0][0], 7: ls.A[0][1], 8: ls.A[1][0], 9: ls.A[1][1], 10: ls.b[0], 11: ls.b[1]}
 
     def forward_jacobian(self, u, p, up, pp, xip, xi, ls):
-        what = (K_FORWARD_WAVE if self.wave else K_FORWARD) | (256 if self.staged else 0)
+        what = (K_FORWARD_WAVE if self.wave else K_FORWARD) | (256 if self.staged else 0) | (512 if self.assign else 0)
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def global_residual(self, u, p, up, pp, xip, xi, ls):
         return self._call(K_RESIDUAL_WAVE if self.wave else K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def adjoint_jacobian(self, u, p, up, pp, xip, xi, g, f, ls):
-        what = (K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0)
+        what = (K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0) | (512 if self.assign else 0)
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls), 12: g, 13: f})
 
     def solve_adjoint_local(self, u, p, up, pp, xip, xi, z_u, z_p, phi, g, f):

@@ -74,6 +74,31 @@ def test_wave_kernels_without_shape_cache(model, params, eps):
         em.lib().c8emu_set_shape_cache(1)
 
 
+@pytest.mark.parametrize("mesh", MESHES)
+def test_staged_assembly_assign_mode(mesh):
+    # c8_set_assign_mode: the row sums assign A and b; on stale content the result is the accumulate-into result on zeros
+    import numpy as np
+    from meshes import prescribed_fields
+    orc, dut, c = make_pair(factory, mesh, "small_J2", CASES[1][1])
+    dut.wave = mesh == "hex8"
+    dut.staged = True
+    u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    ref, xi_ref = dut.new_linsys(), dut.new_state()
+    assert dut.forward_jacobian(u, p, z, zp, dut.new_state(), xi_ref, ref) == 0
+    dut.assign = True
+    ls = dut.new_linsys()
+    for i in range(2):
+        ls.b[i][:] = 3.25
+        for j in range(2):
+            ls.A[i][j][:] = -1.5
+    assert dut.forward_jacobian(u, p, z, zp, dut.new_state(), dut.new_state(), ls) == 0
+    for i in range(2):
+        assert np.array_equal(ls.b[i], ref.b[i])
+        for j in range(2):
+            assert np.array_equal(ls.A[i][j], ref.A[i][j])
+
+
 @pytest.mark.parametrize("model,params,eps", CASES)
 def test_staged_gather_assembly(model, params, eps):
     # staged assembly: element matrices stored element-major, rows summed per node (gather_node_rows)
