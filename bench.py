@@ -139,6 +139,8 @@ def main():
     if args.assign:
         asm.set_assign_mode(True)
     if split:  # staged assembly in two parts: the ghost rows (local nodes nowned .. ntouched) are summed first
+        if args.stage_chunk <= 0:
+            asm.set_stage_chunk(asm.nelems)  # the two-part row sums need the whole part in one staged chunk
         asm.set_gather_early_nodes(part.nowned, part.ntouched)
 
     def step(ev=None):
