@@ -806,7 +806,13 @@ template <class E, int MAXDEG> struct GatherShared {
 template <class E, int MAXDEG> struct GatherLane {
   static constexpr int N00 = (9 * MAXDEG + 63) / 64, N01 = (3 * MAXDEG + 63) / 64;
   static constexpr int NLD = (4 * E::NDOF + 63) / 64;  // loads per lane and element: hex8 2, tet4 1
-  static constexpr int CH = 8;                         // elements whose rows are in flight together
+#ifdef C8_EXPERIMENT_GATHER_CH  // timing experiment
+  static constexpr int CH = C8_EXPERIMENT_GATHER_CH;
+#else
+  // elements whose rows are in flight together in one wavefront.  Two, not all eight: 72 registers and seven waves per
+  // SIMD hide the latency better than eight loads in flight at four waves per SIMD (11.13 against 11.39 ms per assembly)
+  static constexpr int CH = 2;
+#endif
   double v[CH][NLD], rv[CH];
   int pos[CH][NLD];
   double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
