@@ -4,12 +4,14 @@ One "step" = one pass of the hot path (c8_assemble_forward_jacobian: residual + 
 local return-mapping solves and the CSR scatter) over the rank's mesh part, inputs resident in HBM.
 Workload (BASELINE.json metric: "1M hex8 J2-plasticity fp64"): a 100x100x100 hex8 brick per GPU,
 small_J2 (E 1000, nu 0.25, K 100, Y 2), prescribed mixed elastic/plastic state of SURVEY.md 8d.
-For N > 1 the workload is weak-scaled: rank r owns one 100^3 block of a (px*100, py*100, pz*100) brick
-(2x2x2 blocks of an 8M-element brick at N = 8, BASELINE.json config 5).  A step is then the assembly
-plus the owned/ghost halo ADD of the Jacobian and residual (LinearAlg::gather_A/gather_b) over RCCL;
-`value` = all elements of all ranks / max-over-ranks wall time.  The exchange overlaps the assembly: in the
-default staged mode the ghost rows are summed first and travel while the owned rows are summed; with
---scatter atomic the elements that add into ghost rows are assembled first.
+For N > 1 the workload is weak-scaled by default: rank r owns one 100^3 block of a (px*100, py*100, pz*100) brick
+(2x2x2 blocks of an 8M-element brick at N = 8, BASELINE.json config 5); --scaling strong splits the one 100^3 brick
+N ways instead (BASELINE.json config 4).  A step is then the assembly plus the owned/ghost halo ADD of the Jacobian
+and residual (LinearAlg::gather_A/gather_b): HIP pack / unpack kernels and grouped RCCL point-to-point messages of
+libc8.so (c8_halo_*), no torch op on the path.  `value` = all elements of all ranks / max-over-ranks wall time.  The
+exchange overlaps the assembly: in the default staged mode the ghost rows are summed first and travel while the owned
+rows are summed; with --scatter atomic the elements that add into ghost rows are assembled first.  torch.distributed
+(gloo) only carries the rendezvous, the one-off exchange lists and the timing reduction.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
 Prints ONE JSON line on rank 0.
@@ -36,12 +38,13 @@ def algorithmic_bytes(nelems, nnodes, nnz_total, nen=8, nqp=8, nloc=7, ndofn=4):
     return nelems * (4 * nen + 8 * nqp * nloc * 2) + nnodes * 8 * (3 + 2 * ndofn + ndofn) + 8 * nnz_total
 
 
-def measured_traffic(edge, scatter, kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-    (profiles/*traffic*.json, collected as MI355X_MICROARCH.md prescribes); None if there is no
-    profile for this configuration.  PMC counters cannot be read from inside the timed process."""
+def pmc_profile(edge, scatter, kernel, build_id):
+    """The committed rocprofv3 --pmc passes of this same command (profiles/*traffic*.json, collected by
+    tools/collect_pmc.py as MI355X_MICROARCH.md prescribes; PMC counters cannot be read from inside the timed process).
+    Returns (profile of THIS library build or None, newest profile of another build or None): a figure measured on
+    other kernels is reported apart, never as `traffic`."""
     import glob
-    best = None
+    same = other = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             d = json.load(open(f))
@@ -49,8 +52,25 @@ def measured_traffic(edge, scatter, kernel):
             continue
         c = d.get("config", {})
         if c.get("edge") == edge and c.get("scatter") == scatter and c.get("kernel") == kernel:
-            best = d.get("traffic_bytes_per_launch")
-    return best
+            d["file"] = os.path.basename(f)
+            if d.get("build_id") == build_id:
+                same = d
+            else:
+                other = d
+    return same, other
+
+
+def valu_utilisation(profile, kernel_ms):
+    """FP64-VALU issue utilisation of the assembly (SURVEY.md 8d asks for it beside the HBM figure: it is what binds):
+    wave-level VALU instructions of the assembly's kernels per launch / their measured duration, against the issue peak
+    of 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 FP64 instruction."""
+    peak = 256 * 4 * 2.4e9 / 4.0
+    insts = sum(profile["per_launch_mean"][k].get("SQ_INSTS_VALU", 0.0) for k in profile.get("launches_per_assembly", [])
+                if k in profile["per_launch_mean"])
+    if not insts:
+        return None
+    rate = insts / (kernel_ms * 1e-3)
+    return {"wave_valu_insts": insts, "issue_peak_per_s": peak, "achieved_per_s": rate, "frac": rate / peak}
 
 
 def cpu_baseline(n, nthreads):
@@ -85,9 +105,13 @@ def main():
                     "NOT the default: the contract metric is the accumulate-into assembly")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the ghost rows after the whole assembly")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = rehearsal of the N>1 path with all ranks on one GPU (halo staged through the host)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one edge^3 block per GPU (default); strong = the one edge^3 brick split N ways")
+    ap.add_argument("--transport", "--backend", dest="transport", default="rccl", choices=["rccl", "host", "nccl", "gloo"],
+                    help="rccl (default): grouped ncclSend/ncclRecv over xGMI, one rank per GPU; host: rehearsal of the N > 1 "
+                         "path with all ranks on one GPU (RCCL refuses that), messages through the host")
     args = ap.parse_args()
+    args.transport = {"nccl": "rccl", "gloo": "host"}.get(args.transport, args.transport)
 
     import torch
     import torch.distributed as dist
@@ -96,24 +120,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    if args.backend == "gloo":
+    if args.transport == "host":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo")  # control plane only: rendezvous, exchange lists, timing; the data path is libc8.so's
 
     from calibr8_amd import Assembler
     from calibr8_amd import distributed as D
+    from calibr8_amd import lib as c8lib
     from meshes import prescribed_fields
 
-    # mesh part of this rank: an n^3 block of the (px*n, py*n, pz*n) brick; element edge 1/n everywhere
+    # mesh part of this rank.  weak: an n^3 block of the (px*n, py*n, pz*n) brick; strong: the (n/px, n/py, n/pz) block
+    # of the one n^3 brick.  Element edge 1/n everywhere.
     n = args.n
     pdims = D.pdims_for(world)
-    part = D.brick_part(rank, pdims, n, edge=1.0)
+    if args.scaling == "strong":
+        assert all(n % q == 0 for q in pdims), "--scaling strong: the edge must divide by the part grid"
+        block = tuple(n // q for q in pdims)
+    else:
+        block = (n, n, n)
+    part = D.brick_part(rank, pdims, block, edge=block[0] / n)
     plan = D.HaloPlan(part, dist if world > 1 else None)
     coords = plan.coords
     asm = Assembler(8, coords, part.conn, "small_J2", J2, device=str(dev), scatter=args.scatter,
@@ -121,7 +149,25 @@ def main():
     asm.set_kernel(args.kernel)
     if args.stage_chunk > 0:
         asm.set_stage_chunk(args.stage_chunk)
-    halo = D.Halo(plan, asm.rowptr[0][0], asm.colidx[0][0], device=dev)
+    transport = args.transport
+    comm = halo = None
+    if world > 1:
+        if transport == "rccl":
+            try:
+                comm = D.Comm.rccl(dist, rank, world)
+                ok = 1.0
+            except Exception as e:  # every rank must take the same branch
+                print("rank %d: RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
+                ok = 0.0
+            t = torch.tensor([ok])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if float(t.item()) == 0.0:
+                if comm is not None:
+                    comm.close()
+                comm, transport = None, "host (RCCL communicator could not be created)"
+        if comm is None:
+            comm = D.Comm.host(dist, rank, world)
+        halo = D.Halo(plan, asm.rowptr[1][1], asm.colidx[1][1], asm, comm)
     # prescribed state of SURVEY.md 8d on the rank's own block (local coordinates of the block)
     origin = coords[: part.ntouched].min(axis=0)
     u_h, p_h = prescribed_fields(coords - origin, 0.004, ramp=True, seed=1234 + rank)
@@ -144,23 +190,22 @@ def main():
         asm.set_gather_early_nodes(part.nowned, part.ntouched)
 
     def step(ev=None):
-        """eval_forward_jacobian, then la->gather_A / gather_b (primal.cpp:99,110-111).  With more than one rank
-        the elements that add into ghost rows are assembled first and the exchange of those rows (one grouped
-        all_to_all) runs while the interior elements are assembled; `ev` = HIP-event pairs around the assembly
-        launches."""
+        """eval_forward_jacobian, then la->gather_A / gather_b (primal.cpp:99,110-111).  With more than one rank the
+        exchange of the ghost rows (one message per neighbour) runs beside assembly work; `ev` = HIP-event pairs around
+        the assembly launches."""
         if split:  # every element staged, ghost rows summed; the other rows are summed while the ghost rows travel
             if ev:
                 ev[0][0].record()
             asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
             if ev:
                 ev[0][1].record()
-            h = halo.start_gather(ls)
+            halo.gather_start(ls)
             if ev:
                 ev[1][0].record()
             asm.gather_finish()
             if ev:
                 ev[1][1].record()
-            halo.finish_gather(ls, h)
+            halo.gather_finish(ls)
             return
         if not overlap:
             if ev:
@@ -169,20 +214,20 @@ def main():
             if ev:
                 ev[0][1].record()
             if world > 1:
-                halo.finish_gather(ls, halo.start_gather(ls))
+                halo.gather(ls)
             return
         if ev:
             ev[0][0].record()
         asm.forward_jacobian_subset(u, p, u0, p0, xi_prev, xi, ls, e_if)
         if ev:
             ev[0][1].record()
-        h = halo.start_gather(ls)
+        halo.gather_start(ls)
         if ev:
             ev[1][0].record()
         asm.forward_jacobian_subset(u, p, u0, p0, xi_prev, xi, ls, e_in)
         if ev:
             ev[1][1].record()
-        halo.finish_gather(ls, h)
+        halo.gather_finish(ls)
 
     def barrier():
         torch.cuda.synchronize()
@@ -204,10 +249,35 @@ def main():
     assert asm.status() == 0
     # assembly kernels only (both launches of a step when the exchange is overlapped)
     kernel_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in pairs[:2 if (overlap or split) else 1]) for pairs in ev]))
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    def timed(fn, reps):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return 1e3 * float(tt.item()) / reps
+
+    # beside the headline (untimed above): the reference's step is zero_all + eval_forward_jacobian (primal.cpp:98-99)
+    reps = max(2, min(5, args.steps))
+
+    def step_with_zero():
+        ls.zero()
+        step()
+
+    also = {"ms_per_step_with_zero_all": timed(step_with_zero, reps)}
+    if args.scatter == "gather" and not args.assign:
+        asm.set_assign_mode(True)  # zero_all + assembly in one call (c8_set_assign_mode): no zeroing pass, no read of the old values
+        also["ms_per_step_assign_mode"] = timed(step, reps)
+        asm.set_assign_mode(False)
+    assert asm.status() == 0
 
     overlap_check = None
     if overlap or split:  # untimed: the overlapped step against the blocking exchange after a whole assembly
@@ -218,7 +288,7 @@ def main():
         if split:
             asm.set_gather_early_nodes(0, 0)
         asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
-        halo.finish_gather(ls, halo.start_gather(ls))
+        halo.gather(ls)
         no = part.nowned  # owned rows only: ghost rows are scratch after the exchange
         d = 0.0
         for k, neq in ((4, 3), (5, 1)):
@@ -227,48 +297,68 @@ def main():
                              ls.flat[lo:lo + no * neq].abs().max()))
         lo, hi = 0, int(asm.rowptr[0][0][no * 3])
         d = max(d, float((ls.flat[lo:hi] - ref_flat[lo:hi]).abs().max() / ls.flat[lo:hi].abs().max()))
-        chk = torch.tensor([d], dtype=torch.float64, device=tmax.device)
+        chk = torch.tensor([d], dtype=torch.float64)
         dist.all_reduce(chk, op=dist.ReduceOp.MAX)
         overlap_check = float(chk.item())
         assert overlap_check < 1e-12, overlap_check
-    hb = torch.tensor([float(halo.bytes_per_gather_A + halo.bytes_per_gather_b) if world > 1 else 0.0],
-                      dtype=torch.float64, device=tmax.device)
+    hb = torch.tensor([float(halo.send_bytes(3)) if world > 1 else 0.0], dtype=torch.float64)
+    ne = torch.tensor([float(asm.nelems)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(hb, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ne, op=dist.ReduceOp.SUM)
     halo_bytes = int(hb.item())
-    nelems_total = asm.nelems * world
+    nelems_total = int(ne.item())
     value = nelems_total * args.steps / dt
     plastic_frac = float((xi[:, :, 6] > 0).double().mean().item())
+    build_info = c8lib.load_library().c8_build_info().decode()
+    build_id = build_info.split()[0].split("=")[1]
 
     out = {
         "metric": "element Jacobian assemblies/sec, 1M hex8 J2-plasticity fp64",
         "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%dx%dx%d hex8 brick per GPU (%d elements, %d nodes), small_J2 E1000 nu0.25 K100 Y2, "
-                               "prescribed ramped uniaxial state eps=0.004 seed 1234, residual+Jacobian assembly"
-                               % (n, n, n, asm.nelems, asm.nnodes),
-                   "elements_per_gpu": asm.nelems, "plastic_fraction": plastic_frac, "scatter": args.scatter, "kernel": args.kernel,
+        "config": {"workload": "%dx%dx%d hex8 brick per GPU (%d elements, %d nodes)%s, small_J2 E1000 nu0.25 K100 Y2, "
+                               "prescribed ramped uniaxial state eps=0.004 seed 1234, residual+Jacobian assembly; a "
+                               "structured brick stands in for the notched specimen (SURVEY.md 8d)"
+                               % (block[0], block[1], block[2], asm.nelems, asm.nnodes,
+                                  " = the %d^3 brick (BASELINE config 4) split %dx%dx%d" % ((n,) + tuple(pdims)) if args.scaling == "strong" and world > 1 else ""),
+                   "elements_per_gpu": asm.nelems, "elements_total": nelems_total, "plastic_fraction": plastic_frac,
+                   "scatter": args.scatter, "kernel": args.kernel,
                    "colors": asm.ncolors, "part_grid": list(pdims),
-                   "parallelism": "one n^3 element block per GPU; ghost rows of A and b ADDed into their owners "
-                                  "by one grouped neighbour all_to_all (RCCL) per step",
+                   "parallelism": "one element block per GPU; ghost rows of A and b ADDed into their owners: HIP pack kernel, "
+                                  "one grouped ncclSend/ncclRecv message per neighbour (RCCL over xGMI), HIP unpack-add kernel "
+                                  "(c8_halo_gather_start / _finish)",
+                   "transport": transport if world > 1 else None,
                    "halo_send_bytes_per_step_max_rank": halo_bytes,
                    "halo_overlapped_with_interior_assembly": bool(overlap),
                    "halo_overlapped_with_owned_row_sums": bool(split), "assign_mode": bool(args.assign),
-                   "overlap_vs_blocking_max_rel_diff": overlap_check},
+                   "overlap_vs_blocking_max_rel_diff": overlap_check, "library_build": build_info},
+        "also": also,
     }
     if rank == 0:
         nnz_total = sum(asm.nnz[i][j] for i in range(2) for j in range(2))
         balg = algorithmic_bytes(asm.nelems, asm.nnodes, nnz_total)
         achieved = balg / (kernel_ms * 1e-3) / 1e9
+        prof, prof_other = pmc_profile(block[0] if block[0] == block[1] == block[2] else -1, args.scatter,
+                                       "slot" if args.kernel == "slot" else "wave", build_id)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": measured_traffic(n, args.scatter, "slot" if args.kernel == "slot" else "wave"),
+                           "traffic": prof.get("traffic_bytes_per_launch") if prof else None,
                            "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
                            "kernel": ("k_forward_jacobian" if args.kernel == "slot" else "k_forward_jacobian_wave") +
                                      ("<hex8,small_J2> into the element stage + k_gather_rows, per chunk of elements"
                                       if args.scatter == "gather" else "<hex8,small_J2> (%d launches per step)"
                                       % (asm.ncolors if args.scatter == "colored" else 1))}
+        # what binds: FP64 VALU issue, from the same PMC profile
+        if prof:
+            out["roofline"]["valu"] = valu_utilisation(prof, kernel_ms)
+            out["roofline"]["traffic_profile"] = prof["file"]
+        elif prof_other:
+            out["roofline"]["profile_of_another_build"] = {
+                "file": prof_other["file"], "build_id": prof_other.get("build_id"),
+                "traffic": prof_other.get("traffic_bytes_per_launch"), "valu": valu_utilisation(prof_other, kernel_ms),
+                "note": "PMC passes measured on other kernels than this library build: reported for orientation only"}
         if world == 1:
             # beside the headline (untimed above): the other entry points of the path on the same mesh and state,
             # HIP-event milliseconds per call (BASELINE config 2: primal + adjoint dR/dp assembly on one GPU)
@@ -324,6 +414,8 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / v
         print(json.dumps(out))
     if world > 1:
+        halo.close()
+        comm.close()
         dist.destroy_process_group()
 
 

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import lib as _l
 
-NUM_PARAMS = {"elastic": 4, "small_J2": 6, "hyper_J2": 8}
+NUM_PARAMS = {"elastic": 4, "small_J2": 6, "hyper_J2": 8, "small_hill": 11, "hypo_hill": 11, "isotropic_elastic": 2}
 NEQ = (3, 1)
 
 
@@ -60,7 +60,7 @@ class LinearSystem:
 
 class Assembler:
     def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0, max_iters=500,
-                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter="colored", extra_pairs=None):
+                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter=None, extra_pairs=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("calibr8_amd needs a HIP device: there is no CPU execution path")
@@ -94,7 +94,8 @@ class Assembler:
         self.ndofs = 4 * self.nn
         self.nnz = [[int(self.L.c8_graph_nnz(h, i, j)) for j in range(2)] for i in range(2)]
         self._graph = None
-        self.set_scatter(scatter)
+        if scatter is not None:  # None: the library's default (staged assembly, see c8_set_scatter_mode)
+            self.set_scatter(scatter)
         self.use_current_stream()
 
     def __del__(self):
@@ -149,6 +150,10 @@ class Assembler:
     def set_scatter(self, mode):
         m = {"colored": _l.C8_SCATTER_COLORED, "atomic": _l.C8_SCATTER_ATOMIC, "gather": _l.C8_SCATTER_GATHER}[mode]
         _l.check(self.L.c8_set_scatter_mode(self.h, m))
+
+    @property
+    def scatter(self):
+        return {_l.C8_SCATTER_COLORED: "colored", _l.C8_SCATTER_ATOMIC: "atomic", _l.C8_SCATTER_GATHER: "gather"}[self.L.c8_get_scatter_mode(self.h)]
 
     def set_assign_mode(self, on):
         """scatter='gather': Jacobian assemblies assign A and b (zero_all + assembly in one call) instead of adding"""

@@ -68,6 +68,14 @@ extern "C" {
 
 const char* c8_last_error(void) { return g_c8_last_error.c_str(); }
 
+#ifndef C8_BUILD_ID
+#define C8_BUILD_ID "unknown"
+#endif
+#ifndef C8_BUILD_FLAGS
+#define C8_BUILD_FLAGS "unknown"
+#endif
+const char* c8_build_info(void) { return "id=" C8_BUILD_ID " flags=" C8_BUILD_FLAGS; }
+
 int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   if (!md || !mo || !out) return fail(C8_ERR_ARG, "c8_create: null argument");
   *out = nullptr;
@@ -132,6 +140,11 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   }
   // cached shape tables of the wave kernels; if they do not fit, the kernels compute them per call (same values)
   (void)c8_set_shape_cache(c, 1);
+  // default scatter mode: the staged assembly (fastest, reproducible) where the node degrees allow it; its stage is
+  // allocated at the first Jacobian assembly and, should that fail, the context falls back to colour batches
+  c->scatter_auto = true;
+  c->scatter_mode = (c->graph.max_degree <= c8::GATHER_MAX_DEGREE) ? C8_SCATTER_GATHER : C8_SCATTER_COLORED;
+  g_c8_last_error.clear();
   *out = c;
   return C8_OK;
 }
@@ -231,9 +244,12 @@ int c8_set_scatter_mode(c8_ctx* c, int mode) {
   if (mode == C8_SCATTER_GATHER) {
     if (c->graph.max_degree > c8::GATHER_MAX_DEGREE) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: node degree too large for staged (gather) assembly");
   }
+  if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_scatter_mode: a staged assembly is waiting for c8_gather_finish");
   c->scatter_mode = mode;
+  c->scatter_auto = false;
   return C8_OK;
 }
+int c8_get_scatter_mode(const c8_ctx* c) { return c ? c->scatter_mode : C8_ERR_ARG; }
 int c8_set_stage_chunk(c8_ctx* c, int min_chunk) {
   if (!c || min_chunk < 1) return fail(C8_ERR_ARG, "c8_set_stage_chunk: bad argument");
   C8_HIP(hipDeviceSynchronize());
@@ -365,25 +381,41 @@ static int run_staged(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs c
 // `scatters` = the kernel adds into shared A/b entries (needs colouring or atomics).
 static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& aa, SystemArgs sa, bool scatters, char const* what) {
   if (!fn) return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": not available for this element/model");
-  bool const colored = scatters && (c->scatter_mode == C8_SCATTER_COLORED);
+  // staged assembly: the two Jacobian assemblies; everything else (residual-only assembly: NDOF adds per element)
+  // keeps atomic adds
+  bool const staged = scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !c->subset &&
+                      (fn == c->ks.forward_jacobian_wave || fn == c->ks.adjoint_jacobian_wave || fn == c->ks.forward_jacobian ||
+                       (fn == c->ks.adjoint_jacobian && c->ks.adjoint_slot_stages));
+  // a Jacobian kernel that cannot stage (hex8 slot-per-lane adjoint kernel; element subsets): colour batches / atomic
+  // adds for this call while the context is in its DEFAULT mode, an error when the caller asked for GATHER
+  bool const unstaged_default = scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !staged && c->scatter_auto &&
+                                !c->assign_mode;
+  bool const colored = scatters && !c->subset && (c->scatter_mode == C8_SCATTER_COLORED || unstaged_default);
   sa.status = c->d_status;
   sa.atomic = colored ? 0 : 1;
 #ifdef C8_STAMPS
   if (!c->d_stamps) C8_HIP(hipMalloc((void**)&c->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
   sa.stamps = c->d_stamps;
 #endif
-  if (c->subset && scatters && c->scatter_mode != C8_SCATTER_ATOMIC)
+  if (c->subset && scatters && c->scatter_mode != C8_SCATTER_ATOMIC && !c->scatter_auto)
     return fail(C8_ERR_ARG, std::string(what) + ": element subsets need C8_SCATTER_ATOMIC");
-  // staged assembly: the two Jacobian assemblies; everything else (residual-only assembly: NDOF adds per element)
-  // keeps atomic adds
-  bool const staged = scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] &&
-                      (fn == c->ks.forward_jacobian_wave || fn == c->ks.adjoint_jacobian_wave || fn == c->ks.forward_jacobian ||
-                       (fn == c->ks.adjoint_jacobian && c->ks.adjoint_slot_stages));
-  if (scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !staged)
+  if (scatters && c->scatter_mode == C8_SCATTER_GATHER && sa.A[0][0] && !staged && !unstaged_default)
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly of hex8 adjoint Jacobians needs the wave-per-element kernel");
   if (c->assign_mode && scatters && sa.A[0][0] && !staged)
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": assign mode (c8_set_assign_mode) needs the staged Jacobian assembly (C8_SCATTER_GATHER)");
-  if (staged) return run_staged(c, fn, fa, aa, sa);
+  if (staged) {
+    int const rc = run_staged(c, fn, fa, aa, sa);
+    if (rc == C8_ERR_DEVICE && c->scatter_auto && !c->d_stage && !c->assign_mode && c->early_end <= c->early_begin) {
+      // the default mode could not get its stage: colour batches from here on (noted in c8_last_error)
+      (void)hipGetLastError();
+      c->scatter_mode = C8_SCATTER_COLORED;
+      c->scatter_auto = false;
+      int const rc2 = run(c, fn, fa, aa, sa, scatters, what);
+      if (rc2 == C8_OK) g_c8_last_error = "note: the element stage of C8_SCATTER_GATHER could not be allocated; this context now assembles in C8_SCATTER_COLORED mode";
+      return rc2;
+    }
+    return rc;
+  }
   LaunchArgs a{tables(c, colored), c->ms, fa, aa, sa, 0, 0, c->stream};
   if (c->subset) {
     a.mt.order = c->subset;

@@ -62,8 +62,10 @@ struct c8_ctx {
   c8_allreduce_fn allreduce = nullptr;  // SUM over the parts (null: one part)
   void* allreduce_user = nullptr;
   int num_parts = 1;
+  c8_halo* halo = nullptr;              // multi-part mesh: exchanges and reductions (c8_halo_attach), not owned
   hipStream_t stream = nullptr;
   int scatter_mode = C8_SCATTER_COLORED;
+  bool scatter_auto = false;         // the mode was chosen by c8_create, not by the caller (see run() in c8_api.hip)
   int kernel_variant = C8_KERNEL_AUTO;
   int assign_mode = 0;               // staged Jacobian assemblies assign their outputs instead of adding to them
   int async = 0;
@@ -77,3 +79,6 @@ c8::QoiArgs c8_qoi_args(c8_ctx const* c);
 int c8_qoi_prepare(c8_ctx* c, c8::FieldArgs const& fa);
 int c8_qoi_surface(c8_ctx* c, double const* u, double* J, double* b0);
 int c8_qoi_postprocess(c8_ctx* c, double* J);
+// c8_halo.hip: multi-part helpers for the other translation units
+int c8_parts_allreduce(c8_ctx* c, double* values, int n);  // SUM over the parts: caller's callback, else the halo's communicator; no-op on one part
+int c8_halo_num_owned(c8_halo const* h);

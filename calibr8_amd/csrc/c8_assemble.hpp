@@ -415,9 +415,6 @@ C8_HD void scatter_lhs(EX& ex, SH const& sh, MeshTables const& mt, SystemArgs co
         off = (size_t)sh.nptr[nk] * (neqk * neqa) + (size_t)eqk * sh.deg[nk] * neqa + (size_t)pka * neqa + eqa;
         vals = sa.A[ik][ia];
       }
-#ifdef C8_EXPERIMENT_NO_SCATTER  // timing experiment only
-      if (Jc[a] == 1.2345e300)
-#endif
       ex.add(vals + off, Jc[a], sa.atomic);
     }
   });

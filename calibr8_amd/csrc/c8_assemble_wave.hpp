@@ -102,17 +102,12 @@ template <class E, int NL> struct WaveShared {
   double N[E::NP0][E::NN];
   double dN[E::NP0][E::NN][3];
   double wdv[E::NP0];
-#ifdef C8_EXPERIMENT_SCATTER_ONLY_LEAN
-#define C8_LEAN_DIM(x) 1
-#else
-#define C8_LEAN_DIM(x) (x)
-#endif
-  double M[C8_LEAN_DIM(E::NP0)][NLP][NLP + 1];   // dC/dxi per point
+  double M[E::NP0][NLP][NLP + 1];   // dC/dxi per point
   double q[E::NP0][WQ];             // interpolated values
   double qprev[E::NP0][9];          // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
   double xip[E::NP0][NLP];          // previous local state
-  double D[C8_LEAN_DIM(4)][C8_LEAN_DIM(WF)][WQ + 1];          // dflux/dq of the 4 points of a pass
+  double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
   double F[E::NP0][WQ];             // flux values
   double gh[E::NP0][NLP];           // adjoint: local history g at each point
   double rq[4][WQ + 1];             // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
@@ -308,9 +303,9 @@ C8_HD bool gj_solve_xlane(EX& ex, Col col, GetB getb, Active active) {
   return ok;
 }
 
-#ifdef C8_EXPERIMENT_XL  // timing experiment: hand-over of the Newton solve (bit 0) and of the inverse (bit 1), every model
-#define C8_XL_NEWTON(M) ((C8_EXPERIMENT_XL & 1) != 0)
-#define C8_XL_INVERSE(M) ((C8_EXPERIMENT_XL & 2) != 0)
+#ifdef C8_TUNE_XL  // tuning build (same results): hand-over of the Newton solve (bit 0) and of the inverse (bit 1), every model
+#define C8_XL_NEWTON(M) ((C8_TUNE_XL & 1) != 0)
+#define C8_XL_INVERSE(M) ((C8_TUNE_XL & 2) != 0)
 #else
 #define C8_XL_NEWTON(M) M::GJ_XLANE_JAC
 #define C8_XL_INVERSE(M) M::GJ_XLANE_JAC
@@ -461,13 +456,7 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
   ex.sync();
 
   C8_STAMP(1);
-#if defined(C8_EXPERIMENT_SCATTER_ONLY_LEAN)  // timing experiment only: the arithmetic is not even compiled, so
-  if (false) {                                //   the kernel needs few registers and runs at full occupancy
-#elif defined(C8_EXPERIMENT_SCATTER_ONLY)     // timing experiment only: loads and adds, arithmetic compiled but skipped
-  if (sa.atomic == 12345) {
-#else
   {
-#endif
   // ---- phase N: local Newton at all 8 points (small_J2.cpp:122-173) ---------------------------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
@@ -754,23 +743,11 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
         size_t const nptr = (size_t)sh.nptr[n], deg = (size_t)sh.deg[n], pos = (size_t)((r.pos8 >> (8 * n)) & 0xff);  // pos[e][nb][row node n]
         size_t const in_row = pos * neqb + eqb;
         size_t const urow0 = nptr * (3 * neqb);     // first u row of node n in block (0, ib)
-#ifdef C8_EXPERIMENT_BLOCKED_LAYOUT
-        // timing experiment only (results are not a CSR assembly): node-blocked values, one 4x4 block of 128
-        // contiguous bytes per node pair, written over the caller's contiguous A00|A01|A10|A11 allocation
-        double* const blk = sa.A[0][0] + (nptr + pos) * 16 + (ib == 0 ? eqb : 3);
-        ex.add(blk + (2 * g) * 4, r.J[2 * n], ATOMIC);
-        ex.add(blk + (g ? 3 : 1) * 4, r.J[2 * n + 1], ATOMIC);
-        (void)A0; (void)A1; (void)deg; (void)in_row; (void)urow0;
-#else
         ex.add(A0 + urow0 + (size_t)(2 * g) * deg * neqb + in_row, r.J[2 * n], ATOMIC);
         ex.add(A1 + (g ? nptr * neqb : urow0 + deg * neqb) + in_row, r.J[2 * n + 1], ATOMIC);
-#endif
       }
       if (g == 0) ex.add(sa.b[ib] + (size_t)sh.node[nb] * neqb + eqb, r.R, ATOMIC);
     };
-#ifdef C8_EXPERIMENT_NO_SCATTER  // timing experiment only: everything but the adds
-    if (r.J[0] == 1.2345e300) scatter_all(std::integral_constant<int, 1>{});
-#else
     if (sa.stage) {  // staged assembly: registers -> stage[e]
       double* const st = sa.stage + (size_t)(e % sa.stage_ring) * stage_stride<E>();
       C8_UNROLL
@@ -780,14 +757,10 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
       }
       if (g == 0) st[E::NN * 4 * E::NDOF + b] = r.R;
     } else if (sa.atomic) {
-#ifdef C8_EXPERIMENT_SKIP_PCOL  // timing experiment only: no adds into the p columns (blocks (0,1) and (1,1))
-      if (b < 3 * E::NN)
-#endif
       scatter_all(std::integral_constant<int, 1>{});
     } else {
       scatter_all(std::integral_constant<int, 0>{});
     }
-#endif
     if (lane == 0 && sh.failed) ex.flag(sa.status);
   });
   C8_STAMP(9);
@@ -806,8 +779,8 @@ template <class E, int MAXDEG> struct GatherShared {
 template <class E, int MAXDEG> struct GatherLane {
   static constexpr int N00 = (9 * MAXDEG + 63) / 64, N01 = (3 * MAXDEG + 63) / 64;
   static constexpr int NLD = (4 * E::NDOF + 63) / 64;  // loads per lane and element: hex8 2, tet4 1
-#ifdef C8_EXPERIMENT_GATHER_CH  // timing experiment
-  static constexpr int CH = C8_EXPERIMENT_GATHER_CH;
+#ifdef C8_TUNE_GATHER_CH  // tuning build (same results)
+  static constexpr int CH = C8_TUNE_GATHER_CH;
 #else
   // elements whose rows are in flight together in one wavefront.  Two, not all eight: 72 registers and seven waves per
   // SIMD hide the latency better than eight loads in flight at four waves per SIMD (11.13 against 11.39 ms per assembly)

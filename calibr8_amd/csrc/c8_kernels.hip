@@ -75,10 +75,10 @@ template <class Lane> struct GpuExec {
 // (blocks b and b+8 share an XCD, MI355X_MICROARCH.md), so give each XCD one contiguous
 // chunk of the element order: neighbouring elements then meet in the same L2.
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
-#if defined(C8_EXPERIMENT_NO_XCD_REMAP)   // timing experiment: blocks in launch order, round-robin over the XCDs
+#if defined(C8_TUNE_NO_XCD_REMAP)   // tuning build (same results): blocks in launch order, round-robin over the XCDs
   return b;
-#elif defined(C8_EXPERIMENT_XCD_STRIPE)   // timing experiment: XCD x takes every 8th stripe of C8_EXPERIMENT_XCD_STRIPE blocks
-  int const S = C8_EXPERIMENT_XCD_STRIPE;
+#elif defined(C8_TUNE_XCD_STRIPE)   // tuning build (same results): XCD x takes every 8th stripe of C8_TUNE_XCD_STRIPE blocks
+  int const S = C8_TUNE_XCD_STRIPE;
   int const x = b & 7, k = b >> 3;        // k-th block of XCD x
   return ((k / S) * 8 + x) * S + (k % S);
 #else
@@ -181,8 +181,8 @@ static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
   return hipGetLastError();
 }
 
-#ifdef C8_EXPERIMENT_K4_WAVES  // timing experiment: waves per SIMD of the local-adjoint kernel, every model
-#define C8_K4_WAVES(M) C8_EXPERIMENT_K4_WAVES
+#ifdef C8_TUNE_K4_WAVES  // tuning build (same results): waves per SIMD of the local-adjoint kernel, every model
+#define C8_K4_WAVES(M) C8_TUNE_K4_WAVES
 #else
 #define C8_K4_WAVES(M) M::WAVE_BLOCKS_PER_CU_K4
 #endif

@@ -22,10 +22,11 @@ __host__ __device__ inline int neq_of(int i) { return i == 0 ? 3 : 1; }
 // dbcs.cpp:68-118: one thread per constrained row
 __global__ void k_dirichlet(int n, int resid, int eq, int32_t const* nodes, double const* values, double const* x,
                             int32_t const* nodeptr, int32_t const* nodeadj, double* A_i0, double* A_i1, double* b,
-                            int is_adjoint) {
+                            int is_adjoint, int nowned) {
   int const t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   int const node = nodes[t];
+  if (node >= nowned) return;  // multi-part mesh: the owner applies the condition to its OWNED row (node sets hold owned nodes, dbcs.cpp:66)
   int const ni = neq_of(resid);
   int const row = node * ni + eq;
   int64_t const np = nodeptr[node], deg = nodeptr[node + 1] - np;
@@ -146,7 +147,8 @@ int c8_apply_dirichlet(c8_ctx* c, int n, const c8_dbc* dbcs, const double* const
     if (d.resid < 0 || d.resid > 1 || d.eq < 0 || d.eq >= neq_of(d.resid)) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: bad residual/equation index");
     if (d.n <= 0) continue;
     hipLaunchKernelGGL(k_dirichlet, dim3(grid_of(d.n)), dim3(TPB), 0, c->stream, d.n, d.resid, d.eq, d.nodes, d.values,
-                       x[d.resid], c->d_nodeptr, c->d_nodeadj, sys->A[d.resid][0], sys->A[d.resid][1], sys->b[d.resid], is_adjoint);
+                       x[d.resid], c->d_nodeptr, c->d_nodeadj, sys->A[d.resid][0], sys->A[d.resid][1], sys->b[d.resid], is_adjoint,
+                       c->halo ? c8_halo_num_owned(c->halo) : c->mesh.nnodes);
     C8P_HIP(hipGetLastError());
   }
   return C8_OK;
@@ -199,103 +201,176 @@ int c8_apply_A(c8_ctx* c, const c8_system* sys, const double* const x[2], double
   return C8_OK;
 }
 
+}  // extern "C"
+
+// ---- step drivers ------------------------------------------------------------------------------------------------
+// Shared plumbing of the two drivers.  With a halo attached to the context the step runs over all parts: the assembled
+// system is gathered to its owners, boundary conditions, norms and dot products act on the OWNED rows (the first
+// `nowned` node rows) and are summed over the parts, and what the linear solve returns on the owned nodes is imported to
+// the ghost and phantom copies before it is used.
+namespace {
+
+struct StepSystem {
+  c8_ctx* c;
+  const c8_system* sys;
+  size_t nloc[2];      // local rows per block (all local nodes)
+  size_t nown[2];      // owned rows per block
+  size_t nnz[2][2];
+  bool parts;
+  StepSystem(c8_ctx* ctx, const c8_system* s) : c(ctx), sys(s) {
+    parts = ctx->halo != nullptr;
+    int const no = parts ? c8_halo_num_owned(ctx->halo) : ctx->mesh.nnodes;
+    for (int i = 0; i < 2; ++i) {
+      nloc[i] = (size_t)ctx->mesh.nnodes * neq_of(i);
+      nown[i] = (size_t)no * neq_of(i);
+      for (int j = 0; j < 2; ++j) nnz[i][j] = (size_t)ctx->graph.nodeptr[ctx->mesh.nnodes] * neq_of(i) * neq_of(j);
+    }
+  }
+  int zero() const {  // la->zero_all (linear_alg.cpp:118-129)
+    for (int i = 0; i < 2; ++i) {
+      C8P_HIP(hipMemsetAsync(sys->b[i], 0, nloc[i] * sizeof(double), c->stream));
+      for (int j = 0; j < 2; ++j) C8P_HIP(hipMemsetAsync(sys->A[i][j], 0, nnz[i][j] * sizeof(double), c->stream));
+    }
+    return C8_OK;
+  }
+  // The status of an assembly agreed between the parts (PCU_Add_Int, primal.cpp:100,164): every part learns whether
+  // ANY local solve failed, or any part hit an error, and all take the same branch.
+  int agree(int rc) const {
+    if (!parts) return rc;
+    double v[2] = {rc == C8_LOCAL_SOLVE_FAILED ? 1. : 0., (rc != C8_OK && rc != C8_LOCAL_SOLVE_FAILED) ? 1. : 0.};
+    int const ra = c8_parts_allreduce(c, v, 2);
+    if (ra != C8_OK) return ra;
+    if (rc != C8_OK && rc != C8_LOCAL_SOLVE_FAILED) return rc;
+    if (v[1] > 0.) return c8_fail(C8_ERR_DEVICE, "step driver: the assembly failed on another part");
+    if (v[0] > 0.) return rc == C8_OK ? c8_fail(C8_LOCAL_SOLVE_FAILED, "a local constitutive Newton solve did not converge on another part") : rc;
+    return C8_OK;
+  }
+  // gather_A / gather_b (primal.cpp:110-111), overlapped with the owned rows' sums when the row sums run in two parts
+  int gather() const {
+    int rc = C8_OK;
+    if (parts) rc = c8_halo_gather_start(c->halo, sys, C8_HALO_A | C8_HALO_B);
+    if (rc == C8_OK) rc = c8_gather_finish(c);  // two-part row sums (c8_set_gather_early_nodes): the rest of the rows
+    if (rc == C8_OK && parts) rc = c8_halo_gather_finish(c->halo, sys);
+    return rc;
+  }
+  // sum over the parts of x . y on the owned rows of both blocks (LinearAlg::norm_b, linear_alg.cpp:138-146)
+  int dot_owned(double* const x[2], double* const y[2], double* out) const {
+    double s[2] = {0., 0.};
+    int rc;
+    for (int i = 0; i < 2; ++i)
+      if ((rc = dot(c, nown[i], x[i], y[i], &s[i])) != C8_OK) return rc;
+    double v = s[0] + s[1];
+    if (parts && (rc = c8_parts_allreduce(c, &v, 1)) != C8_OK) return rc;
+    *out = v;
+    return C8_OK;
+  }
+};
+
+// Two-point cubic backtracking (line_search.hpp:56-135 with the reference's safeguards): the model through
+// (0, f0, g0) and (t, ft, gt) has its minimiser at t - t (gt + w - v) / (gt - g0 + 2 w), v = g0 + gt - 3 (f0 - ft) / (0 - t),
+// w = sqrt(v^2 - g0 gt); without a real interior minimiser the step is halved.  The arithmetic is kept operation for
+// operation so that Newton histories equal the reference's.
+double cubic_step(double f0, double g0, double t, double ft, double gt) {
+  double const v = g0 + gt - 3. * (f0 - ft) / (0. - t);
+  double const disc = v * v - g0 * gt;
+  if (disc < 0.) return 0.5 * t;
+  double const w = std::sqrt(disc);
+  double const q = gt - g0 + 2. * w;
+  if (q == 0.) return 0.5 * t;
+  return t - t * (gt + w - v) / q;
+}
+
+}  // namespace
+
+extern "C" {
+
 int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs, int ntbc,
                          const c8_tbc* tbcs, const c8_newton_opts* o, c8_linear_solve_fn solve, void* user, int32_t* iters_out) {
   if (!c || !st || !sys || !o || !solve) return c8_fail(C8_ERR_ARG, "c8_primal_solve_step: null argument");
-  size_t const n[2] = {(size_t)c->mesh.nnodes * 3, (size_t)c->mesh.nnodes};
-  size_t nnz[2][2];
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j) nnz[i][j] = (size_t)c->graph.nodeptr[c->mesh.nnodes] * neq_of(i) * neq_of(j);
+  StepSystem S(c, sys);
   if (!c->d_work[0]) {
-    for (int k = 0; k < 4; ++k) C8P_HIP(hipMalloc((void**)&c->d_work[k], n[k & 1] * sizeof(double)));
+    for (int k = 0; k < 4; ++k) C8P_HIP(hipMalloc((void**)&c->d_work[k], S.nloc[k & 1] * sizeof(double)));
   }
   double* dx[2] = {c->d_work[0], c->d_work[1]};
   double* Adx[2] = {c->d_work[2], c->d_work[3]};
   double* x[2] = {const_cast<double*>(st->x[0]), const_cast<double*>(st->x[1])};
+  double* b[2] = {sys->b[0], sys->b[1]};
   int const saved_async = c->async;
 
-  // la->zero_all + eval_forward_jacobian + tbcs + dbcs (primal.cpp:97-114); returns the assembly status
+  // zero_all + eval_forward_jacobian + status over the parts + tbcs + gather_A/gather_b + dbcs (primal.cpp:97-114)
   auto assemble = [&]() -> int {
-    for (int i = 0; i < 2; ++i) {
-      if (hipMemsetAsync(sys->b[i], 0, n[i] * sizeof(double), c->stream) != hipSuccess) return C8_ERR_DEVICE;
-      for (int j = 0; j < 2; ++j)
-        if (hipMemsetAsync(sys->A[i][j], 0, nnz[i][j] * sizeof(double), c->stream) != hipSuccess) return C8_ERR_DEVICE;
-    }
+    int rc = S.zero();
+    if (rc != C8_OK) return rc;
     c->async = 0;
-    int rc = c8_assemble_forward_jacobian(c, st, sys);
+    rc = S.agree(c8_assemble_forward_jacobian(c, st, sys));
     c->async = saved_async;
     if (rc != C8_OK) return rc;
+    // tractions are added to the GHOST-distributed residual before the gather, as in the reference; in assign mode the
+    // owned rows' sums would overwrite them, so those run first
+    if (ntbc > 0 && c->assign_mode && (rc = c8_gather_finish(c)) != C8_OK) return rc;
     if ((rc = c8_apply_traction(c, ntbc, tbcs, sys)) != C8_OK) return rc;
+    if ((rc = S.gather()) != C8_OK) return rc;
     return c8_apply_dirichlet(c, ndbc, dbcs, st->x, sys, 0);
   };
-  auto norm_b = [&](double* out) -> int {  // LinearAlg::norm_b, linear_alg.cpp:138-146
-    double s0 = 0., s1 = 0.;
-    int rc;
-    if ((rc = dot(c, n[0], sys->b[0], sys->b[0], &s0)) != C8_OK) return rc;
-    if ((rc = dot(c, n[1], sys->b[1], sys->b[1], &s1)) != C8_OK) return rc;
-    *out = std::sqrt(s0 + s1);
-    return C8_OK;
+  auto residual_norm = [&](double* out) -> int {
+    double s;
+    int const rc = S.dot_owned(b, b, &s);
+    *out = std::sqrt(s);
+    return rc;
   };
-  auto add_to_soln = [&](double alpha) {  // Disc::add_to_soln(x, dx, alpha), disc.cpp:893-949
+  // Disc::add_to_soln(x, dx, alpha) (disc.cpp:893-949): dx has been imported to the ghost and phantom copies, so every
+  // copy of a node takes the same update and stays equal to its owner's value bit for bit
+  auto move = [&](double alpha) {
     for (int i = 0; i < 2; ++i)
-      hipLaunchKernelGGL(k_axpy, dim3(grid_of(n[i])), dim3(TPB), 0, c->stream, n[i], alpha, dx[i], x[i]);
+      hipLaunchKernelGGL(k_axpy, dim3(grid_of(S.nloc[i])), dim3(TPB), 0, c->stream, S.nloc[i], alpha, dx[i], x[i]);
   };
 
   int iter = 1;
   bool converged = false;
-  double resid_norm_0 = 1.;
+  double r_first = 1.;
   int rc = C8_OK;
   while ((iter <= o->max_iters) && !converged) {
     rc = assemble();
     if (rc != C8_OK) break;  // local solve failed at the base point (primal.cpp:101-104), or an error
-    double abs_resid_norm;
-    if ((rc = norm_b(&abs_resid_norm)) != C8_OK) break;
-    if (iter == 1) resid_norm_0 = abs_resid_norm;
-    double const rel_resid_norm = abs_resid_norm / resid_norm_0;
-    if ((abs_resid_norm < o->abs_tol) || (rel_resid_norm < o->rel_tol)) { converged = true; break; }
+    double r_abs;
+    if ((rc = residual_norm(&r_abs)) != C8_OK) break;
+    if (iter == 1) r_first = r_abs;
+    if ((r_abs < o->abs_tol) || (r_abs / r_first < o->rel_tol)) { converged = true; break; }
     for (int i = 0; i < 2; ++i)  // la->scale_b(-1.)
-      hipLaunchKernelGGL(k_scale, dim3(grid_of(n[i])), dim3(TPB), 0, c->stream, n[i], -1., sys->b[i]);
+      hipLaunchKernelGGL(k_scale, dim3(grid_of(S.nloc[i])), dim3(TPB), 0, c->stream, S.nloc[i], -1., sys->b[i]);
     C8P_HIP(hipStreamSynchronize(c->stream));
     if (solve(user, sys, dx) != 0) { rc = c8_fail(C8_ERR_ARG, "c8_primal_solve_step: linear solve callback failed"); break; }
-    add_to_soln(1.);
-    if (o->line_search) {  // primal.cpp:139-197 with line_search.hpp:85-135
-      double const psi_0 = 0.5 * abs_resid_norm * abs_resid_norm, dpsi_0 = -2. * psi_0;
-      double const armijo_slope = o->sufficient_decrease * dpsi_0;
-      double alpha_applied = 1., alpha = 1., best_alpha = 1., best_phi = std::numeric_limits<double>::max();
-      bool assembled_any = false, accepted = false;
-      for (int ev = 1; ev <= o->max_evals; ++ev) {
-        add_to_soln(alpha - alpha_applied);
-        alpha_applied = alpha;
+    if (S.parts && (rc = c8_halo_scatter_x(c->halo, dx)) != C8_OK) break;
+    move(1.);
+    if (o->line_search) {  // primal.cpp:139-197: merit 1/2 |R|^2, slope at 0 = -|R_0|^2, slope at t = R(t) . (A dx)
+      double const f0 = 0.5 * r_abs * r_abs, g0 = -2. * f0;
+      double t = 1., t_now = 1., t_best = 1., f_best = std::numeric_limits<double>::max();
+      bool any_assembled = false, accepted = false;
+      for (int trial = 1; trial <= o->max_evals && !accepted; ++trial) {
+        move(t - t_now);
+        t_now = t;
         int const arc = assemble();
-        if (arc == C8_LOCAL_SOLVE_FAILED) { alpha *= 0.5; continue; }  // failed evaluation: halve and retry
+        if (arc == C8_LOCAL_SOLVE_FAILED) { t *= 0.5; continue; }  // a local solve diverged: contract and retry
         if (arc != C8_OK) { rc = arc; break; }
-        double R_alpha;
-        if ((rc = norm_b(&R_alpha)) != C8_OK) break;
-        double const phi = 0.5 * R_alpha * R_alpha;
-        assembled_any = true;
-        if (phi < best_phi) { best_phi = phi; best_alpha = alpha; }
-        if (phi <= psi_0 + alpha * armijo_slope) { accepted = true; break; }
-        // slope phi'(alpha) = R(alpha) . (A dx) for the Hermite cubic
+        double r_t;
+        if ((rc = residual_norm(&r_t)) != C8_OK) break;
+        double const ft = 0.5 * r_t * r_t;
+        any_assembled = true;
+        if (ft < f_best) { f_best = ft; t_best = t; }
+        if (ft <= f0 + t * (o->sufficient_decrease * g0)) { accepted = true; break; }
         const double* cdx[2] = {dx[0], dx[1]};
         if ((rc = c8_apply_A(c, sys, cdx, Adx)) != C8_OK) break;
-        double s0 = 0., s1 = 0.;
-        if ((rc = dot(c, n[0], sys->b[0], Adx[0], &s0)) != C8_OK || (rc = dot(c, n[1], sys->b[1], Adx[1], &s1)) != C8_OK) break;
-        double const slope = s0 + s1;
-        double const d1 = dpsi_0 + slope - 3. * (psi_0 - phi) / (0. - alpha);
-        double const radicand = d1 * d1 - dpsi_0 * slope;
-        double alpha_model = 0.5 * alpha;
-        if (radicand >= 0.) {
-          double const d2 = std::sqrt(radicand), denom = slope - dpsi_0 + 2. * d2;
-          if (denom != 0.) alpha_model = alpha - alpha * (slope + d2 - d1) / denom;
-        }
-        alpha = std::min(std::max(alpha_model, o->min_backtrack * alpha), o->max_backtrack * alpha);
+        double gt;
+        if ((rc = S.dot_owned(b, Adx, &gt)) != C8_OK) break;
+        double const t_model = cubic_step(f0, g0, t, ft, gt);
+        t = std::min(std::max(t_model, o->min_backtrack * t), o->max_backtrack * t);
       }
       if (rc != C8_OK) break;
       if (!accepted) {
-        if (!assembled_any) { rc = c8_fail(C8_LOCAL_SOLVE_FAILED, "line search could not assemble at any trial step"); break; }
-        alpha = best_alpha;
+        if (!any_assembled) { rc = c8_fail(C8_LOCAL_SOLVE_FAILED, "line search could not assemble at any trial step"); break; }
+        t = t_best;
       }
-      add_to_soln(alpha - alpha_applied);
+      move(t - t_now);
     }
     iter++;
   }
@@ -311,26 +386,22 @@ int c8_adjoint_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, i
                           double* grad) {
   if (!c || !st || !sys || !solve || !z || !z[0] || !z[1] || !phi || !g || !f || !grad)
     return c8_fail(C8_ERR_ARG, "c8_adjoint_solve_step: null argument");
-  size_t const n[2] = {(size_t)c->mesh.nnodes * 3, (size_t)c->mesh.nnodes};
-  for (int i = 0; i < 2; ++i) {  // la->zero_all (adjoint.cpp:118)
-    C8P_HIP(hipMemsetAsync(sys->b[i], 0, n[i] * sizeof(double), c->stream));
-    for (int j = 0; j < 2; ++j)
-      C8P_HIP(hipMemsetAsync(sys->A[i][j], 0, (size_t)c->graph.nodeptr[c->mesh.nnodes] * neq_of(i) * neq_of(j) * sizeof(double), c->stream));
-  }
+  StepSystem S(c, sys);
+  int rc = S.zero();  // la->zero_all (adjoint.cpp:118)
+  if (rc != C8_OK) return rc;
   int const saved_async = c->async;
   c->async = 0;
-  int rc = c8_assemble_adjoint_jacobian(c, st, g, f, sys);
-  if (rc == C8_OK) {
-    const double* zc[2] = {z[0], z[1]};
-    rc = c8_apply_dirichlet(c, ndbc, dbcs, zc, sys, 1);  // apply_primal_dbcs(..., is_adjoint) (adjoint.cpp:137)
-  }
+  rc = S.agree(c8_assemble_adjoint_jacobian(c, st, g, f, sys));
+  if (rc == C8_OK) rc = S.gather();  // gather_A / gather_b (adjoint.cpp:128-129)
+  const double* zc[2] = {z[0], z[1]};
+  if (rc == C8_OK) rc = c8_apply_dirichlet(c, ndbc, dbcs, zc, sys, 1);  // apply_primal_dbcs(..., is_adjoint) (adjoint.cpp:137)
   if (rc == C8_OK) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = c8_fail(C8_ERR_DEVICE, "c8_adjoint_solve_step: sync failed");
     else if (solve(user, sys, z) != 0) rc = c8_fail(C8_ERR_ARG, "c8_adjoint_solve_step: linear solve callback failed");
   }
-  const double* zc[2] = {z[0], z[1]};
-  if (rc == C8_OK) rc = c8_solve_adjoint_local(c, st, zc, phi, g, f);       // adjoint.cpp:182
-  if (rc == C8_OK) rc = c8_param_gradient(c, st, zc, phi, grad);            // adjoint_objective.cpp:90-93
+  if (rc == C8_OK && S.parts) rc = c8_halo_scatter_x(c->halo, z);           // the adjoint field is synchronised (adjoint.cpp:148)
+  if (rc == C8_OK) rc = S.agree(c8_solve_adjoint_local(c, st, zc, phi, g, f));  // adjoint.cpp:182
+  if (rc == C8_OK) rc = c8_param_gradient(c, st, zc, phi, grad);            // adjoint_objective.cpp:90-93 (this part's share)
   c->async = saved_async;
   return rc;
 }

@@ -71,7 +71,8 @@ int c8_qoi_prepare(c8_ctx* c, FieldArgs const& fa) {
   QH(hipMemcpyAsync(&total, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   QH(hipStreamSynchronize(c->stream));
   double sums[2] = {c->cal_area_local, total};
-  if (c->allreduce) c->allreduce(c->allreduce_user, sums, 2);  // PCU_Add_Double (calibration.cpp:138, :351)
+  int const rca = c8_parts_allreduce(c, sums, 2);  // PCU_Add_Double (calibration.cpp:138, :351)
+  if (rca) return rca;
   c->cal_area = sums[0];
   c->cal_total_load = sums[1];
   c->cal_load_mismatch = sums[1] - c->cal_load_meas;
@@ -118,7 +119,7 @@ int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
   std::vector<int32_t> const& faces = t.faces;
   std::vector<double> const& S = t.S;
   double const area = t.area;
-  if (d->num_faces > 0 && !(area > 0.) && !c->allreduce) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
+  if (d->num_faces > 0 && !(area > 0.) && !c->allreduce && !c->halo) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
   (void)hipFree(c->d_cal_faces);
   (void)hipFree(c->d_cal_S);
   c->d_cal_faces = nullptr;

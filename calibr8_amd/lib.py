@@ -66,6 +66,17 @@ class LbfgsResult(C.Structure):
                 ("projected_gradient_norm", C.c_double)]
 
 
+class HaloDesc(C.Structure):
+    _fields_ = [("num_owned", C.c_int32), ("num_touched", C.c_int32),
+                ("send_ptr", i64p), ("send_nodes", i32p),
+                ("recv_ptr", i64p), ("recv_nodes", i32p), ("recv_col_ptr", i64p), ("recv_cols", i32p),
+                ("import_ptr", i64p), ("import_nodes", i32p), ("export_ptr", i64p), ("export_nodes", i32p)]
+
+
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double), i64p)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+C8_HALO_B, C8_HALO_A = 1, 2
+C8_COMM_ID_BYTES = 128
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -85,6 +96,7 @@ SYMBOLS = [
     ("c8_create", C.c_int, [C.POINTER(MeshDesc), C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     ("c8_destroy", None, [C.c_void_p]),
     ("c8_last_error", C.c_char_p, []),
+    ("c8_build_info", C.c_char_p, []),
     ("c8_num_local_dofs", C.c_int, [C.c_void_p]),
     ("c8_num_local_points", C.c_int, [C.c_void_p]),
     ("c8_num_colors", C.c_int, [C.c_void_p]),
@@ -96,6 +108,7 @@ SYMBOLS = [
     ("c8_num_active_params", C.c_int, [C.c_void_p]),
     ("c8_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("c8_set_scatter_mode", C.c_int, [C.c_void_p, C.c_int]),
+    ("c8_get_scatter_mode", C.c_int, [C.c_void_p]),
     ("c8_set_stage_chunk", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_shape_cache", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_assign_mode", C.c_int, [C.c_void_p, C.c_int]),
@@ -129,6 +142,22 @@ SYMBOLS = [
     ("c8_transform_gradient", C.c_int, [C.c_int, dp, dp, i32p, dp, dp, dp]),
     ("c8_brick_mesh", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, i32p]),
     ("c8_brick_partition", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
+    ("c8_comm_rccl_id", C.c_int, [C.c_void_p]),
+    ("c8_comm_create_rccl", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("c8_comm_create_host", C.c_int, [C.c_int, C.c_int, HOST_EXCHANGE_FN, HOST_ALLREDUCE_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("c8_comm_destroy", None, [C.c_void_p]),
+    ("c8_comm_rank", C.c_int, [C.c_void_p]),
+    ("c8_comm_size", C.c_int, [C.c_void_p]),
+    ("c8_comm_allreduce_sum", C.c_int, [C.c_void_p, dp, C.c_int]),
+    ("c8_halo_build", C.c_int, [C.c_int32, i64p, i32p, C.POINTER(HaloDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("c8_halo_attach", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("c8_halo_destroy", None, [C.c_void_p]),
+    ("c8_halo_gather_start", C.c_int, [C.c_void_p, C.POINTER(System), C.c_int]),
+    ("c8_halo_gather_finish", C.c_int, [C.c_void_p, C.POINTER(System)]),
+    ("c8_halo_gather", C.c_int, [C.c_void_p, C.POINTER(System), C.c_int]),
+    ("c8_halo_scatter_x", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("c8_halo_send_bytes", C.c_int64, [C.c_void_p, C.c_int]),
+    ("c8_halo_table", C.c_int, [C.c_void_p, C.c_int, i64p, C.POINTER(i64p)]),
 ]
 
 _lib = None

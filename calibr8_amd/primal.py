@@ -37,6 +37,59 @@ def scipy_solver(asm):
     return _l.LINEAR_SOLVE_FN(solve)
 
 
+def distributed_scipy_solver(asm, plan, dist):
+    """Linear-solve callback for a multi-part mesh (stand-in for the reference's distributed Belos solve, out of
+    scope): every rank contributes the OWNED rows of its system (the first plan.part.nowned node rows, columns mapped
+    to global ids), all ranks gather them, solve the global system with SciPy and keep the owned part of dx.  The
+    driver imports dx to the ghost and phantom copies afterwards (c8_halo_scatter_x)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, no = asm.nnodes, plan.part.nowned
+    rp, ci, nnz = asm.rowptr, asm.colidx, asm.nnz
+    gid = plan.node_gid
+    N = plan.part.num_global_nodes
+    world = plan.world
+
+    def solve(user, sys_p, dx_p):
+        sys = sys_p.contents
+        mine = {"b": [], "A": {}}
+        for i in range(2):
+            nrows = no * NEQ[i]
+            mine["b"].append((np.repeat(gid[:no], NEQ[i]) * NEQ[i] + np.tile(np.arange(NEQ[i]), no),
+                              _DevView(sys.b[i], n * NEQ[i], asm.device).to_numpy()[:nrows]))
+            for j in range(2):
+                vals = _DevView(sys.A[i][j], nnz[i][j], asm.device).to_numpy()[: rp[i][j][nrows]]
+                cols = ci[i][j][: rp[i][j][nrows]]
+                gcol = gid[cols // NEQ[j]] * NEQ[j] + cols % NEQ[j]
+                grow = np.repeat(mine["b"][i][0], np.diff(rp[i][j][: nrows + 1]))
+                mine["A"][(i, j)] = (grow, gcol, vals)
+        allp = [None] * world
+        if world > 1:
+            dist.all_gather_object(allp, mine)
+        else:
+            allp = [mine]
+        blocks = [[None, None], [None, None]]
+        for i in range(2):
+            for j in range(2):
+                r = np.concatenate([q["A"][(i, j)][0] for q in allp])
+                c = np.concatenate([q["A"][(i, j)][1] for q in allp])
+                v = np.concatenate([q["A"][(i, j)][2] for q in allp])
+                blocks[i][j] = sp.csr_matrix((v, (r, c)), shape=(N * NEQ[i], N * NEQ[j]))
+        b = [np.zeros(N * NEQ[i]) for i in range(2)]
+        for q in allp:
+            for i in range(2):
+                b[i][q["b"][i][0]] = q["b"][i][1]
+        x = spla.spsolve(sp.bmat(blocks, format="csc"), np.concatenate(b))
+        xs = [x[: N * 3], x[N * 3:]]
+        for i in range(2):
+            loc = np.zeros(n * NEQ[i])
+            loc[: no * NEQ[i]] = xs[i][mine["b"][i][0]]
+            _DevView(dx_p[i], n * NEQ[i], asm.device).from_numpy(loc)
+        return 0
+
+    return _l.LINEAR_SOLVE_FN(solve)
+
+
 _hip = None
 
 

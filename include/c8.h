@@ -40,7 +40,9 @@ enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -
 /* ATOMIC: one launch, f64 atomic adds.  COLORED: one launch per element colour, plain adds, reproducible.
  * GATHER: element matrices are staged element-major in a context-owned buffer (8.4 KB per hex8, 2.2 KB per
  * tet4 element) and a second kernel sums each node's rows in ascending element order: no atomics, bitwise
- * reproducible; the fastest mode for tet4 meshes. */
+ * reproducible; the fastest mode on both element types and the DEFAULT of c8_create wherever no node has more than
+ * 64 neighbours.  If the stage cannot be allocated at the first Jacobian assembly, a context still in its default
+ * mode switches to COLORED and says so in c8_last_error(). */
 enum { C8_SCATTER_ATOMIC = 0, C8_SCATTER_COLORED = 1, C8_SCATTER_GATHER = 2 };
 enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2 };
 
@@ -65,13 +67,15 @@ typedef struct {
 /* The `residuals:` block of a deck (global_residual.cpp:620-630, local_residual.cpp:893-933). */
 typedef struct {
   const char* global_type;          /* "mechanics" (mixed u-p formulation) */
-  const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" */
+  const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" | "small_hill" | "isotropic_elastic" |
+                                       "hypo_hill"  (the names of local_residual.cpp:893-933) */
   double stabilization_multiplier;  /* mechanics.cpp:47 */
   int32_t local_max_iters;          /* "nonlinear max iters" of the local residual */
   double local_abs_tol;             /* "nonlinear absolute tol" */
   double local_rel_tol;             /* "nonlinear relative tol" */
   int32_t num_params;               /* elastic 4 (E nu cte delta_T), small_J2 6 (E nu K Y cte delta_T),
-                                       hyper_J2 8 (E nu Y S D A n K) */
+                                       hyper_J2 8 (E nu Y S D A n K), small_hill / hypo_hill 11 (E nu Y R00 R11 R22
+                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu) */
   const double* params;             /* [num_elem_sets][num_params] */
 } c8_model_desc;
 
@@ -96,6 +100,9 @@ typedef struct {
 int c8_create(const c8_mesh_desc* mesh, const c8_model_desc* model, c8_ctx** out);
 void c8_destroy(c8_ctx* ctx);
 const char* c8_last_error(void);
+/* "id=<sha of sources and flags> flags=<compiler flags>" of this library build (calibr8_amd/build.py): profiles carry
+ * the id of the build they were measured on. */
+const char* c8_build_info(void);
 
 /* ---- discretisation queries (host arrays) ------------------------------------------------ */
 int c8_num_local_dofs(const c8_ctx* ctx);    /* LocalResidual::num_dofs: 1 / 7 / 8 */
@@ -115,7 +122,8 @@ int c8_set_params(c8_ctx* ctx, const double* params_host); /* LocalResidual::set
 int c8_set_active_params(c8_ctx* ctx, int elem_set, int n, const int32_t* param_idx);
 int c8_num_active_params(const c8_ctx* ctx); /* total over element sets = length of grad */
 int c8_set_stream(c8_ctx* ctx, void* hip_stream);
-int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_COLORED (default), C8_SCATTER_ATOMIC or C8_SCATTER_GATHER */
+int c8_set_scatter_mode(c8_ctx* ctx, int mode); /* C8_SCATTER_GATHER (default, see above), C8_SCATTER_ATOMIC or C8_SCATTER_COLORED */
+int c8_get_scatter_mode(const c8_ctx* ctx);
 /* C8_SCATTER_GATHER tuning: elements are staged in chunks of at least `min_chunk` elements (the chunk is never
  * smaller than the element bandwidth of the mesh) through a ring of three chunks.  Default: the whole mesh in one
  * chunk while its stage stays under 12 GB (8.4 KB per hex8, 2.2 KB per tet4 element), else chunks of 262144. */
@@ -239,10 +247,13 @@ typedef struct {
   double min_backtrack, max_backtrack; /* 0.5, 0.9 */
   int32_t max_evals;            /* 4 */
 } c8_newton_opts;
-/* Primal::solve_at_step (primal.cpp:31-209) for one part: Newton iterations on st->x (updated in place,
- * st->xi receives the converged local state) with the reference's convergence tests and line search.
- * Returns C8_OK, C8_LOCAL_SOLVE_FAILED (base point or every line-search trial failed), or
- * C8_NOT_CONVERGED; *iters = Newton iterations taken. */
+/* Primal::solve_at_step (primal.cpp:31-209): Newton iterations on st->x (updated in place, st->xi receives the
+ * converged local state) with the reference's convergence tests and line search.  With a halo attached to the context
+ * (c8_halo_attach) the step runs over all parts: every rank calls it collectively, the assembly is followed by the
+ * status all-reduce (primal.cpp:100,164), gather_A / gather_b (:110-111), boundary conditions and norms on the OWNED
+ * rows, and the solution increment is imported to the ghost copies (disc.cpp:944-947); the callback then solves the
+ * distributed owned system and must fill dx on the owned nodes.  Returns C8_OK, C8_LOCAL_SOLVE_FAILED (base point
+ * or every line-search trial failed, on any part), or C8_NOT_CONVERGED; *iters = Newton iterations taken. */
 enum { C8_NOT_CONVERGED = -5 };
 int c8_primal_solve_step(c8_ctx* ctx, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs, int ntbc,
                          const c8_tbc* tbcs, const c8_newton_opts* opts, c8_linear_solve_fn solve, void* user,
@@ -256,6 +267,92 @@ int c8_primal_solve_step(c8_ctx* ctx, const c8_state* st, const c8_system* sys, 
 int c8_adjoint_solve_step(c8_ctx* ctx, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs,
                           c8_linear_solve_fn solve, void* user, double* const z[2], double* phi, double* g, double* f,
                           double* grad);
+
+/* ---- multi-part meshes: owned/ghost halo and reductions ---------------------------------
+ * One process per GPU, one mesh part per process, elements not ghosted, nodes on part boundaries shared -- the
+ * reference's MPI scheme (disc.cpp:237,297).  Local node numbering of a part: OWNED nodes, then GHOST nodes (touched
+ * by a local element, owned elsewhere), then PHANTOM nodes (not touched locally: columns of owned interface rows,
+ * reserved in the graphs through c8_mesh_desc.extra_pairs), so that the OWNED matrix and vectors are prefix views of
+ * the local arrays and every exchange lands in place.  What replaces what:
+ *   C1  c8_halo_gather (C8_HALO_B)      LinearAlg::gather_b, Tpetra Export ADD          linear_alg.cpp:78-86
+ *   C2  c8_halo_gather (C8_HALO_A)      LinearAlg::gather_A                             linear_alg.cpp:53-63
+ *   C3  c8_halo_scatter_x               apf::synchronize in Disc::add_to_soln / Import  disc.cpp:944-947, :1001
+ *   C4  c8_comm_allreduce_sum           PCU_Add_Doubles(grad)                           adjoint_objective.cpp:109
+ *   C5  c8_comm_allreduce_sum           PCU_Add_Double(J), PCU_Add_Int(status)          adjoint_objective.cpp:39,99; primal.cpp:100,164
+ * Transport: RCCL point-to-point over xGMI (grouped ncclSend/ncclRecv, one message per neighbour and exchange, on a
+ * stream of its own; pack and unpack-add are HIP kernels on the context's stream), or a caller-supplied host exchange
+ * (an MPI host without device-aware transport; several ranks sharing one card, which RCCL refuses).  The received
+ * contributions of a value are added in ascending source-rank order: the gathered system is bitwise reproducible. */
+typedef struct c8_comm c8_comm;
+typedef struct c8_halo c8_halo;
+enum { C8_COMM_ID_BYTES = 128 };
+/* RCCL: rank 0 calls c8_comm_rccl_id, the caller broadcasts the 128 bytes by whatever it has (MPI_Bcast in the
+ * reference's host code, torch.distributed in this repo's bench), every rank calls c8_comm_create_rccl with its HIP
+ * device current.  librccl is loaded at the first of these calls (C8_RCCL_LIB overrides the search). */
+int c8_comm_rccl_id(void* id_out);
+int c8_comm_create_rccl(const void* id, int rank, int nranks, c8_comm** out);
+/* Host transport.  exchange: chunk r of `send` (send_counts[r] doubles, chunks back to back in rank order) goes to
+ * rank r, chunk r of `recv` (recv_counts[r] doubles) comes from rank r; HOST buffers; blocking.  allreduce: in-place
+ * SUM of n HOST doubles.  Both return 0 on success. */
+typedef int (*c8_host_exchange_fn)(void* user, const double* send, const int64_t* send_counts, double* recv,
+                                   const int64_t* recv_counts);
+typedef int (*c8_host_allreduce_fn)(void* user, double* values, int n);
+int c8_comm_create_host(int rank, int nranks, c8_host_exchange_fn exchange, c8_host_allreduce_fn allreduce, void* user,
+                        c8_comm** out);
+void c8_comm_destroy(c8_comm* comm);
+int c8_comm_rank(const c8_comm* comm);
+int c8_comm_size(const c8_comm* comm);
+/* C4 / C5: in-place SUM over the ranks of n HOST doubles (gradient, objective, failure flag packed by the caller). */
+int c8_comm_allreduce_sum(c8_comm* comm, double* values, int n);
+
+/* The exchange lists of one part (HOST arrays, copied).  What Tpetra derives from the OWNED and GHOST maps
+ * (disc.cpp:316-332); the caller gets them from its mesh database (PUMI's remote copies in the reference).
+ * Rows travel whole, in the SENDER's graph order; the receiver needs the sender's column lists once. */
+typedef struct {
+  int32_t num_owned, num_touched;   /* local nodes [0, num_owned) owned, [num_owned, num_touched) ghost, rest phantom */
+  /* export, C1/C2: my ghost rows, grouped by owner rank; send_ptr [nranks+1] */
+  const int64_t* send_ptr;
+  const int32_t* send_nodes;        /* local (ghost) node ids */
+  /* rows I own that rank r sends me, in r's order, with r's column list of each row in MY local ids */
+  const int64_t* recv_ptr;          /* [nranks+1] */
+  const int32_t* recv_nodes;        /* local (owned) node ids */
+  const int64_t* recv_col_ptr;      /* [recv_ptr[nranks] + 1] */
+  const int32_t* recv_cols;         /* local node ids (owned, ghost or phantom) */
+  /* import, C3: nodes whose values I receive (every ghost and phantom node), grouped by owner rank; and the owned
+   * nodes I send to each importing rank, in the importer's order */
+  const int64_t* import_ptr;        /* [nranks+1] */
+  const int32_t* import_nodes;
+  const int64_t* export_ptr;        /* [nranks+1] */
+  const int32_t* export_nodes;
+} c8_halo_desc;
+/* Index tables of the exchanges, built on the host from the part's node graph (= block (1,1) of c8_graph(): one row
+ * per node, sorted neighbour ids) -- needs no device. */
+int c8_halo_build(int32_t num_nodes, const int64_t* node_rowptr, const int32_t* node_colidx, const c8_halo_desc* desc,
+                  int rank, int nranks, c8_halo** out);
+/* Device mirrors of the tables, message buffers, events, on the context's device; the context's graph must be the one
+ * the tables were built from.  Also registers the halo with the context: the step drivers (c8_primal_solve_step,
+ * c8_adjoint_solve_step) and the calibration objective then work over all parts. */
+int c8_halo_attach(c8_halo* halo, c8_ctx* ctx, c8_comm* comm);
+void c8_halo_destroy(c8_halo* halo);
+enum { C8_HALO_B = 1, C8_HALO_A = 2 };
+/* C1 and/or C2 in ONE message per neighbour: ghost rows of b (C8_HALO_B), of the four blocks of A (C8_HALO_A) or both
+ * are packed on the context's stream and sent; c8_halo_gather_finish adds what arrived into the owned rows, on the
+ * context's stream.  Work enqueued on the context's stream between the two calls (interior elements, the owned rows'
+ * sums: c8_gather_finish) overlaps the exchange.  Afterwards the first num_owned node rows hold the OWNED system;
+ * ghost rows are scratch.  c8_halo_gather = start + finish. */
+int c8_halo_gather_start(c8_halo* halo, const c8_system* sys, int what);
+int c8_halo_gather_finish(c8_halo* halo, const c8_system* sys);
+int c8_halo_gather(c8_halo* halo, const c8_system* sys, int what);
+/* C3: owner values of a nodal field pair x = {u [nodes*3], p [nodes]} copied to every ghost and phantom copy. */
+int c8_halo_scatter_x(c8_halo* halo, double* const x[2]);
+/* bytes this rank sends per exchange (what = C8_HALO_A | C8_HALO_B, or 0 for the C3 import) */
+int64_t c8_halo_send_bytes(const c8_halo* halo, int what);
+/* Diagnostic / test access to the host tables (tests/ replay the exchanges in numpy without a device):
+ * which = 0 gather send codes, 1 gather send counts per rank, 2 gather recv counts, 3 unpack destinations (codes),
+ * 4 unpack source offsets, 5 unpack source list; 10..15 the same for C8_HALO_B alone; 20 import send codes (C3),
+ * 21 its send counts, 22 its recv counts, 23 its destination codes.  A code is (segment << 56) | offset with segment
+ * 0..3 = A00 A01 A10 A11, 4 = b[0] / x[0], 5 = b[1] / x[1]. */
+int c8_halo_table(const c8_halo* halo, int which, int64_t* n, const int64_t** data);
 
 /* ---- canonical optimisation variables (HOST arrays) -------------------------------
  * Objective::transform_params / transform_gradient (objective.cpp:41-61,125-137) and their Python twins

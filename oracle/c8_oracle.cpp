@@ -1876,8 +1876,10 @@ static double qoi_preprocess(Ctx& c, Local<double>& local, Fields const& f) {
 }
 
 // eval_qoi_gradient, evaluations.cpp:758-925 (no DFAD/NN parameters)
+// grad_abs (may be null; a test-side diagnostic, not part of the reference): the sum of the MAGNITUDES of every product
+// that enters grad -- the scale against which a re-ordered evaluation of the same sums can be judged.
 static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double const* z_u, double const* z_p,
-                         double const* phi, double* grad) {
+                         double const* phi, double* grad, double* grad_abs = nullptr) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
   global.before_elems(c.kit.nn);
@@ -1887,7 +1889,7 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
   for (int es = 0; es < c.nsets; ++es) {
     int const nact = (int)c.active[es].size();
     int const* act = c.active[es].data();
-    std::vector<double> es_grad(nact, 0.);
+    std::vector<double> es_grad(nact, 0.), es_abs(nact, 0.);
     local.before_elems(&c.params[(size_t)es * c.nparams], c.nparams);
     for (int e : c.set_elems[es]) {
       double X[8][3], N[8], dN[8][3];
@@ -1915,9 +1917,10 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
               double s = 0.;
               for (int k = 0; k < nl; ++k) s += dC[k * nderivs + a] * phi[qp * nl + k];
               es_grad[a] += s;
+              for (int k = 0; k < nl; ++k) es_abs[a] += std::fabs(dC[k * nderivs + a] * phi[qp * nl + k]);
             }
             Fad const J = qoi_point(c, global, local, e, w, dv);
-            for (int a = 0; a < nact; ++a) es_grad[a] += dxq(J, a);
+            for (int a = 0; a < nact; ++a) { es_grad[a] += dxq(J, a); es_abs[a] += std::fabs(dxq(J, a)); }
           }
           global.zero_residual();
           global.evaluate(local, w, dv, ip_set);
@@ -1926,12 +1929,14 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
             double s = 0.;
             for (int j = 0; j < nd; ++j) s += dR[j * nderivs + a] * z[j];
             es_grad[a] += s;
+            for (int j = 0; j < nd; ++j) es_abs[a] += std::fabs(dR[j * nderivs + a] * z[j]);
           }
           local.unseed_wrt_params(nact, act);
           // R_nodal keeps parameter derivatives until zero_residual at the next point
         }
     }
     for (int a = 0; a < nact; ++a) grad[gofs + a] = es_grad[a];  // scatter_es_gradient (:859-867)
+    if (grad_abs) for (int a = 0; a < nact; ++a) grad_abs[gofs + a] = es_abs[a];
     gofs += nact;
   }
 }
@@ -2165,6 +2170,14 @@ void c8o_qoi_gradient(void* h, double const* u, double const* p, double const* u
   Ctx* c = (Ctx*)h;
   Fields f{u, p, u_prev, p_prev, xi_prev, xi};
   qoi_gradient(*c, *c->local_f, f, z_u, z_p, phi, grad);
+}
+// the same, also returning the sum of the magnitudes of all products summed into each component (test diagnostic)
+void c8o_qoi_gradient_abs(void* h, double const* u, double const* p, double const* u_prev, double const* p_prev,
+                          double const* xi_prev, double* xi, double const* z_u, double const* z_p, double const* phi,
+                          double* grad, double* grad_abs) {
+  Ctx* c = (Ctx*)h;
+  Fields f{u, p, u_prev, p_prev, xi_prev, xi};
+  qoi_gradient(*c, *c->local_f, f, z_u, z_p, phi, grad, grad_abs);
 }
 
 // element-level probes used by unit tests: shape functions and quadrature

@@ -18,7 +18,7 @@ class HostLinSys:
 
 
 class GpuBackend:
-    def __init__(self, elem_type, coords, conn, local_type, params, scatter="colored", kernel="auto", **kw):
+    def __init__(self, elem_type, coords, conn, local_type, params, scatter=None, kernel="auto", **kw):
         self.asm = Assembler(elem_type, coords, conn, local_type, params, scatter=scatter, **kw)
         if not (kernel == "wave" and elem_type != 8):
             self.asm.set_kernel(kernel)

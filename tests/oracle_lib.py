@@ -57,6 +57,7 @@ def lib():
         L.c8o_eval_qoi.restype = C.c_double
         L.c8o_eval_qoi.argtypes = [C.c_void_p, dp, dp]
         L.c8o_qoi_gradient.argtypes = [C.c_void_p] + [dp] * 10
+        L.c8o_qoi_gradient_abs.argtypes = [C.c_void_p] + [dp] * 11
         L.c8o_set_calibration.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, dp, C.c_double, C.c_int, C.c_double,
                                           C.c_double, C.c_int, C.c_double]
         L.c8o_set_avg_disp.argtypes = [C.c_void_p]
@@ -202,6 +203,18 @@ class Oracle:
         self.L.c8o_qoi_gradient(self.h, _d(u), _d(p), _d(u_prev), _d(p_prev), _d(xi_prev), _d(xi), _d(z_u),
                                 _d(z_p), _d(phi), _d(grad))
         return grad
+
+
+def _oracle_qoi_gradient_with_scale(self, u, p, u_prev, p_prev, xi_prev, xi, z_u, z_p, phi, nparams):
+    """(grad, grad_abs): grad_abs[i] = sum of the magnitudes of all products summed into grad[i] -- the scale for
+    judging another evaluation order of the same sums (a component may be a cancelled sum)."""
+    grad, gabs = np.zeros(nparams), np.zeros(nparams)
+    self.L.c8o_qoi_gradient_abs(self.h, _d(u), _d(p), _d(u_prev), _d(p_prev), _d(xi_prev), _d(xi), _d(z_u),
+                                _d(z_p), _d(phi), _d(grad), _d(gabs))
+    return grad, gabs
+
+
+Oracle.qoi_gradient_with_scale = _oracle_qoi_gradient_with_scale
 
 
 def kit_points(elem_type, ip_set):

@@ -8,7 +8,7 @@ import numpy as np
 
 import oracle_lib as ol
 from meshes import brick, jiggle, prescribed_fields
-from parity import compare_systems, rel_vec
+from parity import compare_systems, rel_csr_rows, rel_vec
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
@@ -47,6 +47,45 @@ def two_steps(orc, c, eps):
     return [(u0, p0, xi0), (u1, p1, xi1), (u2, p2, xi2)]
 
 
+def jacobian_at_state(orc, u, p, up, pp, xip, xi):
+    """The oracle's condensed Jacobian dR/dx at a GIVEN converged local state, as scipy blocks: its adjoint assembly
+    (evaluations.cpp:349-526) evaluates at the stored state and scatters the transpose."""
+    import scipy.sparse as sp
+    ls = orc.new_linsys()
+    orc.adjoint_jacobian(u, p, up, pp, xip, xi, np.zeros((orc.nelems, orc.npts, orc.nloc)),
+                         np.zeros((orc.nelems, orc.npts, 4 * orc.nn)), ls)
+    shape = lambda i, j: (len(orc.rowptr[i][j]) - 1, len(orc.rowptr[j][i]) - 1)
+    T = [[sp.csr_matrix((ls.A[j][i], orc.colidx[j][i], orc.rowptr[j][i]), shape=shape(j, i)).T.tocsr() for j in range(2)]
+         for i in range(2)]
+    for i in range(2):
+        for j in range(2):
+            T[i][j].sort_indices()
+            assert np.array_equal(T[i][j].indices, orc.colidx[i][j])  # structurally symmetric graphs
+    return [[T[i][j].data for j in range(2)] for i in range(2)]
+
+
+def forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip):
+    """Deviations of a forward assembly (ls_d, xd) from the oracle's (ls_o, xo).  The Jacobian is compared directly and,
+    where that exceeds the bar, against the oracle's Jacobian AT THE DEVICE'S converged local state: the map from the
+    local state to dR/dx can be ill-conditioned (hyper_J2 at plastic onset: the power-law flow stress A (alpha +
+    1e-12)^n has curvature ~alpha^(n-2), 1e12 at a first plastic increment of 1e-8), so two states that agree to one
+    unit in the last place (1e-15) give Jacobians that differ by 1e-11 -- in the oracle itself.  Returned: the direct
+    deviations with every A block replaced by min(direct, at-the-same-state), plus both under their own names."""
+    errs = compare_systems(orc, ls_d, ls_o)
+    errs["xi"] = rel_vec(xd, xo)
+    direct = max(errs["A%d%d" % (i, j)] for i in range(2) for j in range(2))
+    same = None
+    if direct > 1e-13:
+        A_at = jacobian_at_state(orc, u, p, up, pp, xip, xd)
+        same = {}
+        for i in range(2):
+            for j in range(2):
+                k = "A%d%d" % (i, j)
+                same[k] = rel_csr_rows(ls_d.A[i][j], A_at[i][j], orc.rowptr[i][j])
+                errs[k] = min(errs[k], same[k])
+    return errs, direct, same
+
+
 def check_forward(orc, dut, c, model, eps, tol):
     st = two_steps(orc, c, eps)
     for n in (1, 2):
@@ -55,9 +94,8 @@ def check_forward(orc, dut, c, model, eps, tol):
         xo, xd = orc.new_state(), dut.new_state()
         assert orc.forward_jacobian(u, p, up, pp, xip, xo, ls_o) == 0
         assert dut.forward_jacobian(u, p, up, pp, xip, xd, ls_d) == 0
-        errs = compare_systems(orc, ls_d, ls_o)
-        errs["xi"] = rel_vec(xd, xo)
-        assert max(errs.values()) < tol, (n, errs)
+        errs, direct, same = forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip)
+        assert max(errs.values()) < tol, (n, errs, direct, same)
     if model == "small_J2" and eps > 0.003:
         assert (st[2][2][:, :, 6] > 0).mean() > 0.3  # the plastic branch really ran
 
@@ -105,12 +143,13 @@ def check_adjoint_chain(orc, dut, c, model, eps, tol):
         errs = {"phi": rel_vec(phi_d, phi_o), "g": rel_vec(g_d, g_o), "f": rel_vec(f_d, f_o)}
         assert max(errs.values()) < tol, ("solve_adjoint_local", n, errs)
         # K5
-        gr_o = orc.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
+        gr_o, gr_scale = orc.qoi_gradient_with_scale(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
         gr_d = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi_o, len(act))
-        # per component, relative; a component that is a cancelled sum (1e-6 of the largest one or less: seed 1598 of the
-        # sweep has dJ/dE = 6e-12 beside 4e-4) is measured against that floor instead of against itself
-        scale = np.maximum(np.abs(gr_o), 1e-6 * np.abs(gr_o).max() + 1e-300)
-        assert (np.abs(gr_d - gr_o) / scale).max() < 1e-11, ("qoi_gradient", n, gr_d, gr_o)
+        # per component at 1e-12.  A component is a sum over all points of products of either sign and may cancel
+        # (sweep seed 478: dJ/dE = 3e-11 beside dJ/dnu = -9e-8): the scale of component i is the sum of the MAGNITUDES
+        # of the products summed into it (>= |component|, equal to it when nothing cancels) -- the forward error bound
+        # of any evaluation order of that sum
+        assert (np.abs(gr_d - gr_o) / np.maximum(gr_scale, 1e-300)).max() < tol, ("qoi_gradient", n, gr_d, gr_o, gr_scale)
         # K6
         assert abs(dut.eval_qoi(u, p) - orc.eval_qoi(u, p)) < tol * max(1.0, abs(orc.eval_qoi(u, p)))
 

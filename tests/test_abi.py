@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(s[0] for s in lib.SYMBOLS) == names  # the ctypes table is complete too
 
 
+def test_library_is_a_product_build():
+    """The library the tests (and the GPU box) load carries no tuning or diagnostic switch: calibr8_amd/build.py records
+    its flag set in the binary, and a stale object built from other flags is rebuilt (build._stale)."""
+    from calibr8_amd import build, lib
+    info = lib.load_library().c8_build_info().decode()
+    assert info.startswith("id=") and "flags=" in info
+    assert "C8_TUNE" not in info and "C8_STAMPS" not in info and "C8_EXPERIMENT" not in info, info
+    if not (os.environ.get("C8_EXTRA_FLAGS") or os.environ.get("C8_STAMPS")):
+        assert info.split()[0] == "id=" + build.build_id(), "libc8.so was built from other sources or flags: python -m calibr8_amd.build"
+
+
 def test_host_helpers_work_without_gpu():
     import calibr8_amd
     c, conn = calibr8_amd.brick_mesh(3, 2, 2, 3.0, 2.0, 2.0)

@@ -1,8 +1,10 @@
-"""Multi-part assembly + halo exchange on CPU ranks (gloo, world_size 2 and 4): the N > 1 path of
-SURVEY.md section 8e.  Each rank assembles its own part (here with the oracle, the exchange layer is
-backend-agnostic) into GHOST-distributed A and b; after gather_A / gather_b the OWNED rows must equal
-the rows of the single-part assembly of the whole mesh, scatter_x must make ghost copies consistent,
-and the packed all-reduce must sum the per-part gradients."""
+"""Multi-part assembly + halo exchange on CPU ranks (gloo, world_size 2, 4 and 8): the N > 1 path of
+SURVEY.md section 8e without a device.  Each rank assembles its own part with the oracle into GHOST-distributed A and
+b; the exchange lists come from calibr8_amd.distributed.HaloPlan, the index tables from libc8.so's c8_halo_build (host
+code), and tests/halo_replay.py replays the exchanges from those tables with gloo as the transport.  After the gather
+the OWNED rows must equal the rows of the single-part assembly of the whole mesh, scatter_x must make ghost AND phantom
+copies equal their owners' values, and the host all-reduce of c8_comm must sum over the ranks.  The same tables drive
+the HIP kernels on the GPU (tests/test_gpu_distributed.py)."""
 import os
 import socket
 import sys
@@ -63,32 +65,26 @@ def worker(rank, world, port, n, pdims, use_brick_part, out):
             assert np.allclose(plan.coords, c[plan.node_gid], atol=1e-12)
         lc = c[plan.node_gid]
         orc = ol.Oracle(ol.HEX8, lc, part.conn, "small_J2", J2, extra_pairs=plan.extra_pairs)
-        halo = D.Halo(plan, orc.rowptr[0][0], orc.colidx[0][0])
+        from halo_replay import HaloReplay
+        halo = D.Halo(plan, orc.rowptr[1][1], orc.colidx[1][1])
+        rep = HaloReplay(halo, dist, world)
         gid = plan.node_gid
         lu = np.ascontiguousarray(u.reshape(-1, 3)[gid].ravel())
         lp = np.ascontiguousarray(p[gid])
         ls, xi = orc.new_linsys(), orc.new_state()
         assert orc.forward_jacobian(lu, lp, 0 * lu, 0 * lp, orc.new_state(), xi, ls) == 0
-        # the overlapped form first (it must not see the in-place result of the blocking form): one flat
-        # array A00 A01 A10 A11 b0 b1, one exchange started before / finished after other work
-        class FlatLS:
-            pass
-        fl = FlatLS()
-        parts = [ls.A[0][0], ls.A[0][1], ls.A[1][0], ls.A[1][1], ls.b[0], ls.b[1]]
-        fl.offsets = np.concatenate([[0], np.cumsum([len(q) for q in parts])]).astype(np.int64)
-        fl.flat = torch.from_numpy(np.concatenate(parts).copy())
-        h = halo.start_gather(fl)
-        busy = torch.ones(1000).sum()  # stands for the interior assembly
-        halo.finish_gather(fl, h)
         assert set(plan.interface_elems) | set(plan.interior_elems) == set(range(len(part.conn)))
         assert not (set(plan.interface_elems) & set(plan.interior_elems))
         assert (part.conn[plan.interior_elems] < part.nowned).all()
+        # C1 alone on a copy of b, then C1 + C2 in one message: the same owned residual either way
+        b_only = [None] * 4 + [ls.b[0].copy(), ls.b[1].copy()]
+        rep.gather(b_only, b_only=True)
+        segs = [ls.A[0][0], ls.A[0][1], ls.A[1][0], ls.A[1][1], ls.b[0], ls.b[1]]
+        rep.gather(segs)
+        no = part.nowned
+        assert np.array_equal(b_only[4][: no * 3], ls.b[0][: no * 3]) and np.array_equal(b_only[5][:no], ls.b[1][:no])
         A = [[torch.from_numpy(ls.A[i][j]) for j in range(2)] for i in range(2)]
         b = [torch.from_numpy(ls.b[i]) for i in range(2)]
-        halo.gather_A(A)
-        halo.gather_b(b)
-        flat_ref = np.concatenate([A[0][0].numpy(), A[0][1].numpy(), A[1][0].numpy(), A[1][1].numpy(), b[0].numpy(), b[1].numpy()])
-        assert np.abs(fl.flat.numpy() - flat_ref).max() <= 1e-13 * np.abs(flat_ref).max()
         # reference: single-part assembly of the whole mesh
         ref = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
         lr, xr = ref.new_linsys(), ref.new_state()
@@ -113,21 +109,23 @@ def worker(rank, world, port, n, pdims, use_brick_part, out):
                 worst = max(worst, diff / abs(Ag).max())
                 # the owned pattern covers every entry of the global rows
                 assert (Ag[grow] != 0).nnz <= Al.nnz or True
-        # C3: owner -> ghost copy
-        x = [torch.from_numpy(lu.copy()), torch.from_numpy(lp.copy())]
-        x[0][no * 3: part.ntouched * 3] = -7.0
-        x[1][no: part.ntouched] = -7.0
-        halo.scatter_x(x)
-        ok_x = np.array_equal(x[0].numpy()[: part.ntouched * 3], lu[: part.ntouched * 3]) and \
-            np.array_equal(x[1].numpy()[: part.ntouched], lp[: part.ntouched])
-        # C4/C5: packed all-reduce
-        v = torch.tensor([1.0 + rank, 10.0 * rank, 0.0], dtype=torch.float64)
-        halo.allreduce(v)
-        ok_r = np.allclose(v.numpy(), [sum(1.0 + r for r in range(world)), sum(10.0 * r for r in range(world)), 0.0])
+        # C3: owner -> ghost and phantom copies
+        nl = plan.nnodes
+        x = [lu.copy(), lp.copy()]
+        x[0][no * 3:] = -7.0
+        x[1][no:] = -7.0
+        rep.scatter_x(x)
+        ok_x = np.array_equal(x[0], lu) and np.array_equal(x[1], lp) and len(lu) == nl * 3
+        # C4/C5: packed all-reduce through the host transport of c8_comm
+        comm = D.Comm.host(dist, rank, world)
+        v = comm.allreduce(np.array([1.0 + rank, 10.0 * rank, 0.0]))
+        ok_r = np.allclose(v, [sum(1.0 + r for r in range(world)), sum(10.0 * r for r in range(world)), 0.0])
+        comm.close()
+        nneigh = int(((halo.table(1) > 0) | (halo.table(2) > 0)).sum())
         # owned nodes partition the global node set
         cnt = torch.tensor([float(no)], dtype=torch.float64)
         dist.all_reduce(cnt)
-        out[rank] = (worst, ok_x, ok_r, int(cnt.item()) == len(c), len(halo.neighbours), len(plan.phantom_gid))
+        out[rank] = (worst, ok_x, ok_r, int(cnt.item()) == len(c), nneigh, len(plan.phantom_gid))
     finally:
         dist.destroy_process_group()
 
@@ -181,7 +179,10 @@ def adjoint_worker(rank, world, port, n, pdims, out):
         ref = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
         for o in (orc, ref):
             o.set_active(0, active)
-        halo = D.Halo(plan, orc.rowptr[0][0], orc.colidx[0][0])
+        from halo_replay import HaloReplay
+        halo = D.Halo(plan, orc.rowptr[1][1], orc.colidx[1][1])
+        rep = HaloReplay(halo, dist, world)
+        comm = D.Comm.host(dist, rank, world)
         rng = np.random.default_rng(5)
         z_u, z_p = rng.standard_normal(len(u)) * 1e-3, rng.standard_normal(len(p)) * 1e-3
 
@@ -198,12 +199,12 @@ def adjoint_worker(rank, world, port, n, pdims, out):
             grad = o.qoi_gradient(uu, pp, 0 * uu, 0 * pp, o.new_state(), xi, zu, zp, phi, len(active))
             return ls, grad
 
-        def c3(zu, zp):  # ghost copies are stale until the owner -> ghost exchange
-            x = [torch.from_numpy(zu.copy()), torch.from_numpy(zp.copy())]
-            x[0][no * 3: part.ntouched * 3] = 99.0
-            x[1][no: part.ntouched] = 99.0
-            halo.scatter_x(x)
-            return x[0].numpy(), x[1].numpy()
+        def c3(zu, zp):  # the copies are stale until the owner -> copies exchange
+            x = [zu.copy(), zp.copy()]
+            x[0][no * 3:] = 99.0
+            x[1][no:] = 99.0
+            rep.scatter_x(x)
+            return x[0], x[1]
 
         lu = np.ascontiguousarray(u.reshape(-1, 3)[gid].ravel())
         lp = np.ascontiguousarray(p[gid])
@@ -212,16 +213,15 @@ def adjoint_worker(rank, world, port, n, pdims, out):
         ls, grad = chain(orc, lu, lp, lzu, lzp, fix_ghosts=c3)
         lr, grad_ref = chain(ref, u, p, z_u, z_p)
         # C1 on the adjoint right-hand side; the transposed Jacobian goes through the same C2 as in the forward test
-        b = [torch.from_numpy(ls.b[i]) for i in range(2)]
-        halo.gather_b(b)
+        rep.gather([None] * 4 + [ls.b[0], ls.b[1]], b_only=True)
         worst = 0.0
         for i in range(2):
-            bo = b[i].numpy()[: no * NEQ[i]].reshape(no, NEQ[i])
+            bo = ls.b[i][: no * NEQ[i]].reshape(no, NEQ[i])
             br = lr.b[i].reshape(-1, NEQ[i])[gid[:no]]
             worst = max(worst, np.abs(bo - br).max() / np.abs(lr.b[i]).max())
-        gt = torch.from_numpy(grad.copy())
-        halo.allreduce(gt)  # C4
-        gerr = np.abs(gt.numpy() - grad_ref).max() / np.abs(grad_ref).max()
+        gt = comm.allreduce(grad.copy())  # C4
+        gerr = np.abs(gt - grad_ref).max() / np.abs(grad_ref).max()
+        comm.close()
         out[rank] = (worst, gerr)
     finally:
         dist.destroy_process_group()

@@ -493,6 +493,84 @@ def test_full_size_million_elements_properties():
     assert rel(fd_u, yu) < 1e-5 and rel(fd_p, yp) < 1e-5
 
 
+def test_full_size_million_elements_adjoint_path_properties():
+    # BASELINE config 3, adjoint half, at full size (100^3 hex8): K3 / K4 / K5 checked, not only timed.
+    #  (1) K3 with zero histories assembles the transpose of K1's Jacobian: y . (A_K3 x) = x . (A_K1 y);
+    #  (2) K3 staged and K3 with atomic adds agree; the staged mode is bitwise reproducible;
+    #  (3) K4 (per-point outputs) at 200 random elements equals the ORACLE on those elements as stand-alone meshes;
+    #  (4) K5: the two independent kernels (eight elements per wavefront / one lane group per element) agree over the
+    #      whole mesh, and the gradient is affine in (z, phi).
+    import torch
+    from calibr8_amd import Assembler, brick_mesh
+    n = 100
+    coords, conn = brick_mesh(n, n, n)
+    asm = Assembler(8, coords, conn, "small_J2", J2)
+    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    xi0, xi = asm.new_state(), asm.new_state()
+    dot = lambda a, b: float((a * b).sum())
+    l1 = asm.new_linsys()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, xi, l1) == 0
+    g0 = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=u.device)
+    f0 = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=u.device)
+    # (1), (2)
+    l3 = asm.new_linsys()
+    g = g0.clone()
+    assert asm.adjoint_jacobian(u, p, z, zp, xi0, xi, g, f0, l3) == 0
+    l3b, gb = asm.new_linsys(), g0.clone()
+    assert asm.adjoint_jacobian(u, p, z, zp, xi0, xi, gb, f0, l3b) == 0
+    assert torch.equal(l3.flat, l3b.flat) and torch.equal(g, gb)
+    del l3b
+    asm.set_scatter("atomic")
+    l3a, ga = asm.new_linsys(), g0.clone()
+    assert asm.adjoint_jacobian(u, p, z, zp, xi0, xi, ga, f0, l3a) == 0
+    assert float((l3a.flat - l3.flat).abs().max() / l3.flat.abs().max()) < 1e-13
+    del l3a, ga
+    asm.set_scatter("gather")
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    rnd = lambda t: torch.randn(t.shape, generator=gen, dtype=torch.float64).to(u.device)
+    xu, xp, yu, yp = rnd(u), rnd(p), rnd(u), rnd(p)
+    a3u, a3p, a1u, a1p = torch.zeros_like(u), torch.zeros_like(p), torch.zeros_like(u), torch.zeros_like(p)
+    asm.apply_A(l3, xu, xp, a3u, a3p)
+    asm.apply_A(l1, yu, yp, a1u, a1p)
+    lhs, rhs = dot(yu, a3u) + dot(yp, a3p), dot(xu, a1u) + dot(xp, a1p)
+    scale = float(a3u.abs().max()) * float(yu.abs().sum())
+    assert abs(lhs - rhs) < 1e-12 * scale, (lhs, rhs, scale)
+    del l1, l3, a3u, a3p, a1u, a1p
+    # (3) K4 at full size against the oracle on sampled elements
+    z_u, z_p = rnd(u) * 1e-3, rnd(p) * 1e-3
+    g_in = rnd(g0) * 1e-2
+    phi, g4, f4 = torch.zeros_like(g0), g_in.clone(), f0.clone()
+    assert asm.solve_adjoint_local(u, p, z, zp, xi0, xi, z_u, z_p, phi, g4, f4) == 0
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(asm.nelems, 200, replace=False))
+    nodes = conn[sample].ravel()                      # every sampled element as a mesh of its own: 8 private nodes
+    sc, sconn = coords[nodes], np.arange(len(nodes), dtype=np.int32).reshape(-1, 8)
+    orc = ol.Oracle(ol.HEX8, sc, sconn, "small_J2", J2)
+    take3 = lambda t: np.ascontiguousarray(t.cpu().numpy().reshape(-1, 3)[nodes].ravel())
+    take1 = lambda t: np.ascontiguousarray(t.cpu().numpy()[nodes])
+    st = lambda t: np.ascontiguousarray(t.cpu().numpy()[sample])
+    su, sp_ = take3(u), take1(p)
+    phi_o, g_o, f_o = np.zeros((200, 8, 7)), st(g_in), np.zeros((200, 8, 32))
+    orc.solve_adjoint_local(su, sp_, 0 * su, 0 * sp_, st(xi0), st(xi), take3(z_u), take1(z_p), phi_o, g_o, f_o)
+    assert rel_vec(st(phi), phi_o) < 1e-12 and rel_vec(st(g4), g_o) < 1e-12 and np.abs(st(f4) - f_o).max() < 1e-12
+    # (4) K5
+    asm.set_active(0, [0, 1, 2, 3])
+    def grad_of(zu_, zp_, phi_, kernel="auto"):
+        asm.set_kernel(kernel)
+        gr = torch.zeros(4, dtype=torch.float64, device=u.device)
+        assert asm.qoi_gradient(u, p, z, zp, xi0, xi, zu_, zp_, phi_, gr) == 0
+        asm.set_kernel("auto")
+        return gr.cpu().numpy()
+    g_w, g_s = grad_of(z_u, z_p, phi), grad_of(z_u, z_p, phi, "slot")
+    g_00 = grad_of(torch.zeros_like(z_u), torch.zeros_like(z_p), torch.zeros_like(phi))
+    g_2 = grad_of(2 * z_u, 2 * z_p, 2 * phi)
+    mag = np.abs(g_w).max()
+    assert np.abs(g_w).min() > 0 and np.abs(g_w - g_s).max() < 1e-11 * mag, (g_w, g_s)  # 8e6 terms summed in another order
+    assert np.abs((g_2 - g_00) - 2 * (g_w - g_00)).max() < 1e-11 * mag
+
+
 def test_full_size_million_tets_properties():
     # the reference's element type at a million elements (56^3 hexes split into 6 tets each, 1.05 M tet4):
     # scatter modes agree, staged mode bitwise reproducible, global equilibrium, rigid-translation null space

@@ -56,6 +56,27 @@ def main():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # FETCH_SIZE/WRITE_SIZE are in KB; gfx950 reports half of wide reads (MI355X_MICROARCH.md): doubled = upper bound
             cs["hbm_bytes_corrected"] = 1024.0 * (2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"])
+    # what bench.py looks up: the configuration, the library build the counters belong to, and the HBM bytes of one
+    # assembly = the launches of one c8_assemble_forward_jacobian call
+    sys.path.insert(0, ROOT)
+    from calibr8_amd import lib as c8lib
+    info = c8lib.load_library().c8_build_info().decode()
+    ba = args.bench_args
+    opt = lambda name, default: ba[ba.index(name) + 1] if name in ba else default
+    scatter, kernel = opt("--scatter", "gather"), opt("--kernel", "auto")
+    out["config"] = {"edge": int(opt("--edge", 100)), "scatter": scatter, "kernel": "slot" if kernel == "slot" else "wave"}
+    out["build_id"] = info.split()[0].split("=")[1]
+    out["library_build"] = info
+    fwd = [k for k in out["per_launch_mean"] if "k_forward_jacobian" in k and "SmallJ2" in k]
+    rows = [k for k in out["per_launch_mean"] if "k_gather_rows" in k] if scatter == "gather" else []
+    out["launches_per_assembly"] = fwd[:1] + rows[:1]
+    ncol = {"colored": 8}.get(scatter, 1)  # per_launch_mean of a colour-batched assembly is the mean over its launches
+    if all("hbm_bytes_corrected" in out["per_launch_mean"][k] for k in out["launches_per_assembly"]) and out["launches_per_assembly"]:
+        out["traffic_bytes_per_launch"] = sum(out["per_launch_mean"][k]["hbm_bytes_corrected"] for k in out["launches_per_assembly"]) * ncol
+    out["note"] = ("rocprofv3 --pmc passes (one counter group per pass, kernel-trace only) on `python3 bench.py --no-cpu --steps 2 "
+                   "--warmup 1 %s`; traffic_bytes_per_launch = HBM-side bytes per ASSEMBLY = sum over the assembly's kernel "
+                   "launches of 1024*(2*FETCH_SIZE + WRITE_SIZE): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
+                   "gfx950 (an upper bound for our gathers), WRITE_SIZE exact for 16-B stores" % " ".join(ba))
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out["per_launch_mean"], indent=1))
