@@ -242,7 +242,10 @@ def test_two_parts_hip_assembly_and_halo_match_single_part_and_oracle():
         assert res["xi"] < 1e-14 and res["k3_g"] < 1e-14, (r, res["xi"], res["k3_g"])
         assert res["split_bitwise_equals_blocking"], r
         assert res["c1"] < 1e-12 and res["c1_leaves_A"] and res["c3"] and res["c45"], (r, res)
-        assert res["bytes"][0] > res["bytes"][1] > 0 and res["bytes"][2] > 0
+        assert res["bytes"][0] >= res["bytes"][1] >= 0
+    # rank 0 (lowest part id) owns every node it shares: it sends no ghost rows but exports values (C3); rank 1 the reverse
+    assert sum(out[r]["bytes"][0] for r in range(2)) > sum(out[r]["bytes"][1] for r in range(2)) > 0
+    assert sum(out[r]["bytes"][2] for r in range(2)) > 0
     assert sum(out[r]["phantoms"] for r in range(2)) > 0
 
 
