@@ -189,42 +189,51 @@ using std::pow;
 using std::sqrt;
 
 // ---------------------------------------------------------------------------
-// 3x3 tensor algebra (the MiniTensor subset the hot models use, a15 of
-// SURVEY.md section 8a): norm (Frobenius), trace, transpose, eye, det, inverse, dev.
+// Tensor algebra (the MiniTensor subset the hot models use, a15 of SURVEY.md section 8a):
+// norm (Frobenius), trace, transpose, eye, det, inverse, dev.  MiniTensor tensors carry a
+// RUN-TIME dimension (defines.hpp:31-37): 3 in 3-D, 2 in the 2-D decks (tri3), where every
+// model runs on 2 x 2 tensors (small_J2.cpp:187 `eye<T>(ndims)`).  Here a tensor is stored
+// 3 x 3 with `dim`; the entries outside dim x dim are zero and stay zero under every
+// operation below, so sums over all nine entries equal the sums over dim x dim bit for bit.
 // ---------------------------------------------------------------------------
 template <class T> struct Tens {
-  T a[3][3];
+  T a[3][3] = {};
+  int dim = 3;
   T& operator()(int i, int j) { return a[i][j]; }
   T const& operator()(int i, int j) const { return a[i][j]; }
 };
 template <class T> struct Vec {
-  T a[3];
+  T a[3] = {};
   T& operator()(int i) { return a[i]; }
   T const& operator()(int i) const { return a[i]; }
 };
 template <class S> struct is_tens : std::false_type {};
 template <class T> struct is_tens<Tens<T>> : std::true_type {};
 
-template <class T> Tens<T> eye() {
+template <class T> Tens<T> eye(int dim = 3) {
   Tens<T> r;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = (i == j) ? 1. : 0.;
+  r.dim = dim;
+  for (int i = 0; i < dim; ++i) for (int j = 0; j < dim; ++j) r(i, j) = (i == j) ? 1. : 0.;
   return r;
 }
 template <class T> Tens<T> operator+(Tens<T> const& A, Tens<T> const& B) {
   Tens<T> r;
+  r.dim = A.dim;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = A(i, j) + B(i, j);
   return r;
 }
 template <class T> Tens<T> operator-(Tens<T> const& A, Tens<T> const& B) {
   Tens<T> r;
+  r.dim = A.dim;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = A(i, j) - B(i, j);
   return r;
 }
 template <class T> Tens<T> operator*(Tens<T> const& A, Tens<T> const& B) {
   Tens<T> r;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+  r.dim = A.dim;
+  for (int i = 0; i < A.dim; ++i) for (int j = 0; j < A.dim; ++j) {
     T s = A(i, 0) * B(0, j);
-    for (int k = 1; k < 3; ++k) s += A(i, k) * B(k, j);
+    for (int k = 1; k < A.dim; ++k) s += A(i, k) * B(k, j);
     r(i, j) = s;
   }
   return r;
@@ -232,27 +241,32 @@ template <class T> Tens<T> operator*(Tens<T> const& A, Tens<T> const& B) {
 template <class S, class T, typename std::enable_if<!is_tens<S>::value, int>::type = 0>
 Tens<T> operator*(S const& s, Tens<T> const& A) {
   Tens<T> r;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = s * A(i, j);
+  r.dim = A.dim;
+  for (int i = 0; i < A.dim; ++i) for (int j = 0; j < A.dim; ++j) r(i, j) = s * A(i, j);
   return r;
 }
 template <class S, class T, typename std::enable_if<!is_tens<S>::value, int>::type = 0>
 Tens<T> operator*(Tens<T> const& A, S const& s) {
   Tens<T> r;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = A(i, j) * s;
+  r.dim = A.dim;
+  for (int i = 0; i < A.dim; ++i) for (int j = 0; j < A.dim; ++j) r(i, j) = A(i, j) * s;
   return r;
 }
 template <class S, class T> Tens<T> operator/(Tens<T> const& A, S const& s) {
   Tens<T> r;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = A(i, j) / s;
+  r.dim = A.dim;
+  for (int i = 0; i < A.dim; ++i) for (int j = 0; j < A.dim; ++j) r(i, j) = A(i, j) / s;
   return r;
 }
 template <class T> Tens<T> transpose(Tens<T> const& A) {
   Tens<T> r;
+  r.dim = A.dim;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = A(j, i);
   return r;
 }
 template <class T> T trace(Tens<T> const& A) { return A(0, 0) + A(1, 1) + A(2, 2); }
 template <class T> T det(Tens<T> const& A) {
+  if (A.dim == 2) return A(0, 0) * A(1, 1) - A(1, 0) * A(0, 1);
   return -A(0, 2) * A(1, 1) * A(2, 0) + A(0, 1) * A(1, 2) * A(2, 0) +
          A(0, 2) * A(1, 0) * A(2, 1) - A(0, 0) * A(1, 2) * A(2, 1) -
          A(0, 1) * A(1, 0) * A(2, 2) + A(0, 0) * A(1, 1) * A(2, 2);
@@ -260,6 +274,12 @@ template <class T> T det(Tens<T> const& A) {
 template <class T> Tens<T> inverse(Tens<T> const& A) {
   T const dt = det(A);
   Tens<T> B;
+  B.dim = A.dim;
+  if (A.dim == 2) {
+    B(0, 0) = A(1, 1) / dt; B(0, 1) = -A(0, 1) / dt;
+    B(1, 0) = -A(1, 0) / dt; B(1, 1) = A(0, 0) / dt;
+    return B;
+  }
   B(0, 0) = -A(1, 2) * A(2, 1) + A(1, 1) * A(2, 2);
   B(0, 1) = A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2);
   B(0, 2) = -A(0, 2) * A(1, 1) + A(0, 1) * A(1, 2);
@@ -272,8 +292,8 @@ template <class T> Tens<T> inverse(Tens<T> const& A) {
   return B / dt;
 }
 template <class T> Tens<T> dev(Tens<T> const& A) {
-  T const th = trace(A) / 3.;
-  return A - th * eye<T>();
+  T const th = trace(A) / 3.;  // only 3-D models call this
+  return A - th * eye<T>(A.dim);
 }
 template <class T> T norm(Tens<T> const& A) {
   T s = A(0, 0) * A(0, 0);
@@ -342,7 +362,7 @@ static void full_piv_lu_solve(int n, int m, double const* A_in, double const* B_
 // Element kit (weight.cpp:9-12, evaluations.cpp:82-85 -> apf getBF/getGradBF/
 // getIntPoint/getIntWeight/getDV; mechanics.cpp:103-113 get_size).
 // ---------------------------------------------------------------------------
-enum { TET4 = 4, HEX8 = 8 };
+enum { TRI3 = 3, TET4 = 4, HEX8 = 8 };
 
 struct ElemKit {
   int type, nn, nedges;
@@ -356,7 +376,21 @@ static ElemKit make_kit(int type) {
   ElemKit k;
   std::memset(&k, 0, sizeof(k));
   k.type = type;
-  if (type == TET4) {
+  if (type == TRI3) {  // the reference's 2-D element (disc.cpp:165)
+    k.nn = 3;
+    k.nedges = 3;
+    int const e[3][2] = {{0, 1}, {1, 2}, {2, 0}};
+    std::memcpy(k.edges, e, sizeof(e));
+    // ip set 0: order 1: centroid, weight 1/2; ip set 1: order 2: three interior points, weight 1/6 each (apf's
+    // triangle rules, third party; any degree-2 rule integrates the pressure-mass term exactly)
+    k.npts[0] = 1;
+    k.pts[0][0][0] = k.pts[0][0][1] = 1. / 3.;
+    k.wts[0][0] = 0.5;
+    k.npts[1] = 3;
+    double const a = 1. / 6., b = 2. / 3.;
+    double const q[3][2] = {{b, a}, {a, b}, {a, a}};
+    for (int p = 0; p < 3; ++p) { k.pts[1][p][0] = q[p][0]; k.pts[1][p][1] = q[p][1]; k.wts[1][p] = 1. / 6.; }
+  } else if (type == TET4) {
     k.nn = 4;
     k.nedges = 6;
     int const e[6][2] = {{0, 1}, {1, 2}, {2, 0}, {0, 3}, {1, 3}, {2, 3}};
@@ -394,8 +428,15 @@ static ElemKit make_kit(int type) {
   return k;
 }
 
+static int kit_dims(int type) { return type == TRI3 ? 2 : 3; }
+
 static void shape(int type, double const* xi, double* N, double dNdxi[][3]) {
-  if (type == TET4) {
+  if (type == TRI3) {
+    N[0] = 1. - xi[0] - xi[1];
+    N[1] = xi[0]; N[2] = xi[1];
+    double const g[3][3] = {{-1, -1, 0}, {1, 0, 0}, {0, 1, 0}};
+    std::memcpy(dNdxi, g, sizeof(g));
+  } else if (type == TET4) {
     N[0] = 1. - xi[0] - xi[1] - xi[2];
     N[1] = xi[0]; N[2] = xi[1]; N[3] = xi[2];
     double const g[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
@@ -418,8 +459,10 @@ static double shape_global(int type, int nn, double const X[][3], double const* 
                            double* N, double dN[][3]) {
   double dNdxi[8][3];
   shape(type, xi, N, dNdxi);
+  int const nd = kit_dims(type);
   Tens<double> J;  // J(a,b) = d x_b / d xi_a
-  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+  J.dim = nd;
+  for (int a = 0; a < nd; ++a) for (int b = 0; b < nd; ++b) {
     double s = 0.;
     for (int n = 0; n < nn; ++n) s += dNdxi[n][a] * X[n][b];
     J(a, b) = s;
@@ -428,8 +471,8 @@ static double shape_global(int type, int nn, double const X[][3], double const* 
   for (int n = 0; n < nn; ++n)
     for (int b = 0; b < 3; ++b) {
       double s = 0.;
-      for (int a = 0; a < 3; ++a) s += Ji(b, a) * dNdxi[n][a];
-      dN[n][b] = s;
+      for (int a = 0; a < nd; ++a) s += Ji(b, a) * dNdxi[n][a];
+      dN[n][b] = b < nd ? s : 0.;
     }
   return det(J);
 }
@@ -445,7 +488,7 @@ enum { ELASTIC_PATH = 0, PLASTIC_PATH = 1 };
 template <class T> struct Local;
 
 template <class T> struct Global {
-  int nn = 0, ndofs = 0;
+  int nn = 0, ndofs = 0, ndims = 3;
   int neq[2] = {3, 1};
   int off[2] = {0, 0};
   double stab_mult = 1.;
@@ -456,11 +499,14 @@ template <class T> struct Global {
   Tens<T> F, F_prev, cof_F;
   T det_F;
 
-  void before_elems(int nn_) {  // global_residual.cpp:102-143
+  void before_elems(int nn_, int ndims_ = 3) {  // global_residual.cpp:102-143; mechanics.cpp:16-55: u has ndims equations
     nn = nn_;
+    ndims = ndims_;
+    neq[0] = ndims;
     off[0] = 0;
-    off[1] = 3 * nn;
-    ndofs = 4 * nn;
+    off[1] = ndims * nn;
+    ndofs = (ndims + 1) * nn;
+    F.dim = F_prev.dim = cof_F.dim = ndims;
   }
   int dx_idx(int i, int n, int eq) const { return off[i] + n * neq[i] + eq; }
 
@@ -471,9 +517,9 @@ template <class T> struct Global {
   void gather(double const* u, double const* p, double const* u_prev, double const* p_prev,
               int const* nodes) {  // :181-198 (assigning a double resets derivatives)
     for (int n = 0; n < nn; ++n) {
-      for (int eq = 0; eq < 3; ++eq) {
-        x_nodal[0][n][eq] = u[nodes[n] * 3 + eq];
-        x_prev_nodal[0][n][eq] = u_prev[nodes[n] * 3 + eq];
+      for (int eq = 0; eq < ndims; ++eq) {
+        x_nodal[0][n][eq] = u[nodes[n] * ndims + eq];
+        x_prev_nodal[0][n][eq] = u_prev[nodes[n] * ndims + eq];
       }
       x_nodal[1][n][0] = p[nodes[n]];
       x_prev_nodal[1][n][0] = p_prev[nodes[n]];
@@ -499,7 +545,7 @@ template <class T> struct Global {
       }
     for (int i = 0; i < 2; ++i)
       for (int eq = 0; eq < neq[i]; ++eq)
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < ndims; ++d) {
           grad_x[i][eq][d] = x_nodal[i][0][eq] * dN[0][d];
           grad_x_prev[i][eq][d] = x_prev_nodal[i][0][eq] * dN[0][d];
           for (int n = 1; n < nn; ++n) {
@@ -510,8 +556,8 @@ template <class T> struct Global {
     compute_kinematics();
   }
   void compute_kinematics() {  // mechanics.cpp:62-101
-    for (int k = 0; k < 3; ++k) {
-      for (int l = 0; l < 3; ++l) {
+    for (int k = 0; k < ndims; ++k) {
+      for (int l = 0; l < ndims; ++l) {
         F(k, l) = grad_x[0][k][l];
         F_prev(k, l) = grad_x_prev[0][k][l];
       }
@@ -520,6 +566,13 @@ template <class T> struct Global {
     }
     det_F = det(F);
     Tens<T>& C = cof_F;
+    if (ndims == 2) {  // :95-100
+      C(0, 0) = F(1, 1);
+      C(0, 1) = -F(1, 0);
+      C(1, 0) = -F(0, 1);
+      C(1, 1) = F(0, 0);
+      return;
+    }
     C(0, 0) = F(1, 1) * F(2, 2) - F(1, 2) * F(2, 1);
     C(0, 1) = -F(1, 0) * F(2, 2) + F(1, 2) * F(2, 0);
     C(0, 2) = F(1, 0) * F(2, 1) - F(1, 1) * F(2, 0);
@@ -531,13 +584,13 @@ template <class T> struct Global {
     C(2, 2) = F(0, 0) * F(1, 1) - F(0, 1) * F(1, 0);
   }
   T scalar_x(int i) const { return x[i][0]; }
-  Vec<T> vector_x(int i) const { Vec<T> v; for (int d = 0; d < 3; ++d) v(d) = x[i][d]; return v; }
-  Vec<T> grad_scalar_x(int i) const { Vec<T> v; for (int d = 0; d < 3; ++d) v(d) = grad_x[i][0][d]; return v; }
+  Vec<T> vector_x(int i) const { Vec<T> v; for (int d = 0; d < ndims; ++d) v(d) = x[i][d]; return v; }
+  Vec<T> grad_scalar_x(int i) const { Vec<T> v; for (int d = 0; d < ndims; ++d) v(d) = grad_x[i][0][d]; return v; }
   Tens<T> grad_vector_x(int i) const {
-    Tens<T> t; for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) t(k, l) = grad_x[i][k][l]; return t;
+    Tens<T> t; t.dim = ndims; for (int k = 0; k < ndims; ++k) for (int l = 0; l < ndims; ++l) t(k, l) = grad_x[i][k][l]; return t;
   }
   Tens<T> grad_vector_x_prev(int i) const {
-    Tens<T> t; for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) t(k, l) = grad_x_prev[i][k][l]; return t;
+    Tens<T> t; t.dim = ndims; for (int k = 0; k < ndims; ++k) for (int l = 0; l < ndims; ++l) t(k, l) = grad_x_prev[i][k][l]; return t;
   }
 
   // mechanics.cpp:116-145, 148-227, 230-240 (mixed formulation)
@@ -591,7 +644,7 @@ template <class T> T compute_mu(T const& E, T const& nu) { return E / (2. * (1. 
 template <class T> T compute_kappa(T const& E, T const& nu) { return E / (3. * (1. - 2. * (nu))); }  // :20
 
 template <class T> struct Local {
-  int nres = 0;
+  int nres = 0, ndims = 3;
   int neq[3] = {0, 0, 0};
   int off[3] = {0, 0, 0};
   int ndofs = 0;
@@ -631,6 +684,12 @@ template <class T> struct Local {
   // symmetric tensors are packed (00,01,02,11,12,22) (:206-216, :336-341, :572-577)
   Tens<T> sym(T const* s) const {
     Tens<T> t;
+    t.dim = ndims;
+    if (ndims == 2) {  // (00,01,11)
+      t(0, 0) = s[0]; t(0, 1) = s[1];
+      t(1, 0) = s[1]; t(1, 1) = s[2];
+      return t;
+    }
     t(0, 0) = s[0]; t(0, 1) = s[1]; t(0, 2) = s[2];
     t(1, 0) = s[1]; t(1, 1) = s[3]; t(1, 2) = s[4];
     t(2, 0) = s[2]; t(2, 1) = s[4]; t(2, 2) = s[5];
@@ -645,6 +704,7 @@ template <class T> struct Local {
   void add_to_xi(double const* dxi);                  // (:420-424, :478-492)
   void set_sym_tensor_R(int i, Tens<T> const& t) {  // :565-579
     T* r = &R[off[i]];
+    if (ndims == 2) { r[0] = t(0, 0); r[1] = t(0, 1); r[2] = t(1, 1); return; }
     r[0] = t(0, 0); r[1] = t(0, 1); r[2] = t(0, 2); r[3] = t(1, 1); r[4] = t(1, 2); r[5] = t(2, 2);
   }
   void set_scalar_R(int i, T const& v) { R[off[i]] = v; }
@@ -674,6 +734,7 @@ template <> void Local<double>::jacobian(int, double*) const {}
 template <> void Local<double>::set_scalar_xi_val(int i, double v) { xi[off[i]] = v; }
 template <> void Local<double>::set_sym_tensor_xi_val(int i, Tens<double> const& t) {
   double* s = &xi[off[i]];
+  if (ndims == 2) { s[0] = t(0, 0); s[1] = t(0, 1); s[2] = t(1, 1); return; }
   s[0] = t(0, 0); s[1] = t(0, 1); s[2] = t(0, 2); s[3] = t(1, 1); s[4] = t(1, 2); s[5] = t(2, 2);
 }
 template <> void Local<double>::add_to_xi(double const* dxi) { for (int k = 0; k < ndofs; ++k) xi[k] += dxi[k]; }
@@ -715,6 +776,7 @@ template <> void Local<Fad>::jacobian(int nderivs, double* J) const {
 template <> void Local<Fad>::set_scalar_xi_val(int i, double v) { xi[off[i]].v = v; }
 template <> void Local<Fad>::set_sym_tensor_xi_val(int i, Tens<Fad> const& t) {
   Fad* s = &xi[off[i]];
+  if (ndims == 2) { s[0].v = t(0, 0).v; s[1].v = t(0, 1).v; s[2].v = t(1, 1).v; return; }
   s[0].v = t(0, 0).v; s[1].v = t(0, 1).v; s[2].v = t(0, 2).v;
   s[3].v = t(1, 1).v; s[4].v = t(1, 2).v; s[5].v = t(2, 2).v;
 }
@@ -782,9 +844,12 @@ template <class T> struct Elastic : Local<T> {
 
 // small_J2.cpp (pstrain SYM_TENSOR + alpha SCALAR; params E, nu, K, Y, cte, delta_T)
 template <class T> struct SmallJ2 : Local<T> {
-  SmallJ2() { this->nres = 2; this->neq[0] = 6; this->neq[1] = 1; this->finish_layout(); }
+  explicit SmallJ2(int ndims = 3) {  // get_num_eqs(SYM_TENSOR, ndims) = 6 or 3 (small_J2.cpp:45-51)
+    this->ndims = ndims;
+    this->nres = 2; this->neq[0] = (ndims == 3) ? 6 : 3; this->neq[1] = 1; this->finish_layout();
+  }
   int num_params() const override { return 6; }
-  void init_variables(double* xi_pt) const override { for (int k = 0; k < 7; ++k) xi_pt[k] = 0.; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < this->ndofs; ++k) xi_pt[k] = 0.; }
   bool is_finite_deformation() const override { return false; }
   int solve_nonlinear(Global<T>& g) override {  // :122-173
     if (std::is_same<T, double>::value) return 0;
@@ -838,12 +903,12 @@ template <class T> struct SmallJ2 : Local<T> {
   }
   Tens<T> cauchy(Global<T>& g) override {  // :253-263
     T const p = g.scalar_x(1);
-    Tens<T> const I = eye<T>();
+    Tens<T> const I = eye<T>(g.ndims);
     Tens<T> const dev_sigma = this->dev_cauchy(g);
     return dev_sigma - p * I;
   }
   Tens<T> dev_cauchy(Global<T>& g) override {  // :266-277
-    Tens<T> const I = eye<T>();
+    Tens<T> const I = eye<T>(g.ndims);
     T const E = this->params[0];
     T const nu = this->params[1];
     T const mu = compute_mu(E, nu);
@@ -989,6 +1054,104 @@ template <class T> struct SmallHill : Local<T> {
     return (2. * mu) * (dev_eps - pstrain);
   }
   T hydro_cauchy(Global<T>& g) override {  // :298-306
+    T const kappa = compute_kappa(this->params[0], this->params[1]);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    return kappa * trace(eps);
+  }
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
+// small_hill_plane_strain.cpp (2-D: pstrain SYM_TENSOR (00,01,11), alpha SCALAR; params E nu Y S D R00 R11 R22 R01;
+// R02 = R12 = 1): the in-plane deviatoric stress is completed with s_zz = 2 mu (-tr(eps)/3 + tr(pstrain)) for the Hill
+// function (:226-233); the flow direction is the in-plane part of the 3-D Hill normal (:243-247); no equation is replaced
+template <class T> struct SmallHillPlaneStrain : Local<T> {
+  SmallHillPlaneStrain() { this->ndims = 2; this->nres = 2; this->neq[0] = 3; this->neq[1] = 1; this->finish_layout(); }
+  int num_params() const override { return 9; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 4; ++k) xi_pt[k] = 0.; }
+  bool is_finite_deformation() const override { return false; }
+  int solve_nonlinear(Global<T>& g) override {  // :133-185
+    if (std::is_same<T, double>::value) return 0;
+    {
+      Tens<T> const pstrain_old = this->sym_tensor_xi_prev(0);
+      T const alpha_old = this->scalar_xi_prev(1);
+      this->set_sym_tensor_xi_val(0, pstrain_old);
+      this->set_scalar_xi_val(1, val(alpha_old));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :193-277
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2], S = this->params[3], D = this->params[4];
+    T const R00 = this->params[5], R11 = this->params[6], R22 = this->params[7], R01 = this->params[8];
+    T const R02 = 1., R12 = 1.;
+    T const mu = compute_mu(E, nu);
+    auto inv2 = [](T const& r) { return 1. / (r * r); };  // std::pow(r, -2)
+    T hp[6];  // compute_hill_params (yield_functions.hpp:35-50)
+    hp[0] = 0.5 * (inv2(R11) + inv2(R22) - inv2(R00));
+    hp[1] = 0.5 * (inv2(R22) + inv2(R00) - inv2(R11));
+    hp[2] = 0.5 * (inv2(R00) + inv2(R11) - inv2(R22));
+    hp[3] = 1.5 * inv2(R12);
+    hp[4] = 1.5 * inv2(R02);
+    hp[5] = 1.5 * inv2(R01);
+    Tens<T> const pstrain_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    Tens<T> const s_2D = this->dev_cauchy(g);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const epsilon = 0.5 * (grad_u + transpose(grad_u));
+    T const s_zz = 2. * mu * (-trace(epsilon) / 3. + trace(pstrain));
+    Tens<T> s = s_2D;  // insert_2D_tensor_into_3D
+    s.dim = 3;
+    s(2, 2) = s_zz;
+    T const d12 = s(1, 1) - s(2, 2), d20 = s(2, 2) - s(0, 0), d01 = s(0, 0) - s(1, 1);
+    T const hill = sqrt(hp[0] * d12 * d12 + hp[1] * d20 * d20 + hp[2] * d01 * d01 +
+                        2. * (hp[3] * s(1, 2) * s(1, 2) + hp[4] * s(0, 2) * s(0, 2) + hp[5] * s(0, 1) * s(0, 1)));
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    Tens<T> R_pstrain;
+    T R_alpha;
+    if (plastic) {
+      Tens<T> n;  // in-plane part of compute_hill_normal
+      n.dim = 2;
+      n(0, 0) = ((hp[1] + hp[2]) * s(0, 0) - hp[2] * s(1, 1) - hp[1] * s(2, 2)) / hill;
+      n(1, 1) = ((hp[0] + hp[2]) * s(1, 1) - hp[2] * s(0, 0) - hp[0] * s(2, 2)) / hill;
+      n(0, 1) = (hp[5] * s(0, 1)) / hill;
+      n(1, 0) = n(0, 1);
+      T const dgam = alpha - alpha_old;
+      R_pstrain = pstrain - pstrain_old - dgam * n;
+      R_alpha = f;
+    } else {
+      R_pstrain = pstrain - pstrain_old;
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_pstrain);
+    this->set_scalar_R(1, R_alpha);
+    return path;
+  }
+  Tens<T> cauchy(Global<T>& g) override {  // :280-290
+    T const p = g.scalar_x(1);
+    return this->dev_cauchy(g) - p * eye<T>(g.ndims);
+  }
+  Tens<T> dev_cauchy(Global<T>& g) override {  // :293-304
+    Tens<T> const I = eye<T>(g.ndims);
+    T const mu = compute_mu(this->params[0], this->params[1]);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    Tens<T> const dev_eps = eps - (trace(eps) / 3.) * I;
+    return (2. * mu) * (dev_eps - pstrain);
+  }
+  T hydro_cauchy(Global<T>& g) override {  // :307-315
     T const kappa = compute_kappa(this->params[0], this->params[1]);
     Tens<T> const grad_u = g.grad_vector_x(0);
     Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
@@ -1263,8 +1426,8 @@ template <class T> void Global<T>::evaluate(Local<T>& local, double w, double dv
     Tens<T> stress = local.cauchy(*this);
     if (local.is_finite_deformation()) stress = stress * cof_F;  // PK1 = sigma cof(F)
     for (int n = 0; n < nn; ++n)
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
+      for (int i = 0; i < ndims; ++i)
+        for (int j = 0; j < ndims; ++j) {
           double const dbasis_dx = dN[n][j];
           R_nodal[0][n][i] += stress(i, j) * dbasis_dx * w * dv;
         }
@@ -1277,7 +1440,7 @@ template <class T> void Global<T>::evaluate(Local<T>& local, double w, double dv
   T pressure_scale_factor = local.pressure_scale_factor();
   if (ip_set == 0) {
     Vec<T> const grad_p = grad_scalar_x(1);
-    Tens<T> const I = eye<T>();
+    Tens<T> const I = eye<T>(ndims);
     T hydro_cauchy = local.hydro_cauchy(*this);
     for (int n = 0; n < nn; ++n) {
       double const basis = N[n];
@@ -1287,8 +1450,8 @@ template <class T> void Global<T>::evaluate(Local<T>& local, double w, double dv
     Tens<T> stab_matrix = tau * I;
     if (local.is_finite_deformation()) stab_matrix = stab_matrix * (transpose(cof_F) * cof_F) / det_F;
     for (int n = 0; n < nn; ++n)
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
+      for (int i = 0; i < ndims; ++i)
+        for (int j = 0; j < ndims; ++j) {
           double const dbasis_dx = dN[n][i];
           R_nodal[1][n][0] -= stab_matrix(i, j) * grad_p(j) * dbasis_dx * w * dv;
         }
@@ -1300,7 +1463,12 @@ template <class T> void Global<T>::evaluate(Local<T>& local, double w, double dv
   }
 }
 
-template <class T> Local<T>* make_local(std::string const& type) {  // local_residual.cpp:893-933
+template <class T> Local<T>* make_local(std::string const& type, int ndims = 3) {  // local_residual.cpp:893-933
+  if (ndims == 2) {  // the 2-D decks of the reference that run the 3-D classes on 2 x 2 tensors
+    if (type == "small_J2") return new SmallJ2<T>(2);
+    if (type == "small_hill_plane_strain") return new SmallHillPlaneStrain<T>();
+    return nullptr;
+  }
   if (type == "elastic") return new Elastic<T>();
   if (type == "small_J2") return new SmallJ2<T>();
   if (type == "hyper_J2") return new HyperJ2<T>();
@@ -1316,6 +1484,7 @@ template <class T> Local<T>* make_local(std::string const& type) {  // local_res
 // ---------------------------------------------------------------------------
 struct Ctx {
   ElemKit kit;
+  int ndims = 3;
   int nnodes = 0, nelems = 0, nsets = 1;
   std::vector<double> coords;
   std::vector<int> conn;
@@ -1370,7 +1539,7 @@ static void build_graph(Ctx& c) {
   }
   c.nodeadj.resize(c.nodeptr[c.nnodes]);
   for (int n = 0; n < c.nnodes; ++n) std::copy(adj[n].begin(), adj[n].end(), c.nodeadj.begin() + c.nodeptr[n]);
-  int const neq[2] = {3, 1};
+  int const neq[2] = {c.ndims, 1};
   for (int i = 0; i < 2; ++i)
     for (int j = 0; j < 2; ++j) {
       auto& rp = c.rowptr[i][j];
@@ -1463,7 +1632,7 @@ static int forward_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, LinSys& 
                             int e_begin, int e_end, std::vector<int> const* elist = nullptr) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   int nderivs = -1;
   std::vector<double> dC_dxi(64), dC_dx(8 * NMAX), dxi_dx(8 * NMAX), dtotal(NMAX * NMAX), resid(NMAX);
@@ -1525,7 +1694,7 @@ static int forward_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, LinSys& 
 static void global_residual(Ctx& c, Local<double>& local, Fields const& f, LinSys& ls) {
   Global<double> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn, nl = local.ndofs;
   std::vector<double> resid(NMAX);
   for (int es = 0; es < c.nsets; ++es) {
@@ -1558,8 +1727,8 @@ static void global_residual(Ctx& c, Local<double>& local, Fields const& f, LinSy
 template <class T> static T avg_disp_point(Global<T> const& g, double w, double dv) {
   T value_pt = 0.;
   Vec<T> const u = g.vector_x(0);
-  for (int i = 0; i < 3; ++i) value_pt += u(i) * w * dv;
-  value_pt /= 3;
+  for (int i = 0; i < g.ndims; ++i) value_pt += u(i) * w * dv;
+  value_pt /= g.ndims;
   return value_pt;
 }
 static double dxq(Fad const& v, int j) { return v.dx(j); }
@@ -1674,7 +1843,7 @@ static void adjoint_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, double*
                              LinSys& ls) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   int nderivs = -1;
   std::vector<double> dC_dxi(64), dC_dx(8 * NMAX), dxi_dx(8 * NMAX), dtotal(NMAX * NMAX), dtotalT(NMAX * NMAX),
@@ -1752,7 +1921,7 @@ static void solve_adjoint_local(Ctx& c, Local<Fad>& local, Fields const& f, doub
                                 double* phi, double* g_hist, double* f_hist) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   int nderivs = -1;
   std::vector<double> dC(8 * NMAX), dR(NMAX * NMAX), A(64), rhs(8), phi_pt(8), z(NMAX);
@@ -1765,7 +1934,7 @@ static void solve_adjoint_local(Ctx& c, Local<Fad>& local, Fields const& f, doub
       global.gather(f.u, f.p, f.u_prev, f.p_prev, &c.conn[e * nn]);
       for (int n = 0; n < nn; ++n) {  // gather_adjoint, global_residual.cpp:423-438
         int const node = c.conn[e * nn + n];
-        for (int eq = 0; eq < 3; ++eq) z[global.dx_idx(0, n, eq)] = z_u[node * 3 + eq];
+        for (int eq = 0; eq < c.ndims; ++eq) z[global.dx_idx(0, n, eq)] = z_u[node * c.ndims + eq];
         z[global.dx_idx(1, n, 0)] = z_p[node];
       }
       for (int pt = 0; pt < c.kit.npts[0]; ++pt) {
@@ -1821,7 +1990,7 @@ static void solve_adjoint_local(Ctx& c, Local<Fad>& local, Fields const& f, doub
 // eval_qoi, evaluations.cpp:662-756 (average displacement)
 static double eval_qoi(Ctx& c, Local<double>& local, Fields const& f) {
   Global<double> global;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn;
   double J = 0.;
   for (int es = 0; es < c.nsets; ++es)
@@ -1848,7 +2017,7 @@ static double qoi_preprocess(Ctx& c, Local<double>& local, Fields const& f) {
   if (c.qoi_kind != 1) return 0.;
   Global<double> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn, nl = local.ndofs;
   double total = 0.;
   for (int es = 0; es < c.nsets; ++es) {
@@ -1882,7 +2051,7 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
                          double const* phi, double* grad, double* grad_abs = nullptr) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn);
+  global.before_elems(c.kit.nn, c.ndims);
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   std::vector<double> dC(8 * NMAX), dR(NMAX * NMAX), z(NMAX);
   int gofs = 0;
@@ -1898,7 +2067,7 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
       global.gather(f.u, f.p, f.u_prev, f.p_prev, &c.conn[e * nn]);
       for (int n = 0; n < nn; ++n) {
         int const node = c.conn[e * nn + n];
-        for (int eq = 0; eq < 3; ++eq) z[global.dx_idx(0, n, eq)] = z_u[node * 3 + eq];
+        for (int eq = 0; eq < c.ndims; ++eq) z[global.dx_idx(0, n, eq)] = z_u[node * c.ndims + eq];
         z[global.dx_idx(1, n, 0)] = z_p[node];
       }
       for (int ip_set = 0; ip_set < 2; ++ip_set)
@@ -1956,9 +2125,10 @@ extern "C" {
 void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, int const* conn,
                  int const* elem_set, int nsets, char const* local_type, double stab_mult, int max_iters,
                  double abs_tol, double rel_tol, double const* params, int nparams, int nextra, int const* extra_pairs) {
-  if (elem_type != TET4 && elem_type != HEX8) return nullptr;
+  if (elem_type != TET4 && elem_type != HEX8 && elem_type != TRI3) return nullptr;
   Ctx* c = new Ctx();
   c->kit = make_kit(elem_type);
+  c->ndims = kit_dims(elem_type);  // coords stay [nnodes][3] (z = 0 in 2-D); u is [nnodes][ndims]
   c->nnodes = nnodes;
   c->nelems = nelems;
   c->nsets = nsets;
@@ -1975,8 +2145,8 @@ void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, in
   c->max_iters = max_iters;
   c->abs_tol = abs_tol;
   c->rel_tol = rel_tol;
-  c->local_d = make_local<double>(c->local_type);
-  c->local_f = make_local<Fad>(c->local_type);
+  c->local_d = make_local<double>(c->local_type, c->ndims);
+  c->local_f = make_local<Fad>(c->local_type, c->ndims);
   if (!c->local_d || c->local_d->num_params() != nparams) { delete c; return nullptr; }
   c->local_d->max_iters = c->local_f->max_iters = max_iters;
   c->local_d->abs_tol = c->local_f->abs_tol = abs_tol;
@@ -1993,6 +2163,7 @@ void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, in
 }
 void c8o_destroy(void* h) { delete (Ctx*)h; }
 int c8o_nloc(void* h) { return ((Ctx*)h)->nloc; }
+int c8o_ndims(void* h) { return ((Ctx*)h)->ndims; }
 int c8o_npts(void* h) { return ((Ctx*)h)->ngpts; }
 void c8o_set_params(void* h, double const* params) {
   Ctx* c = (Ctx*)h;

@@ -20,11 +20,14 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-NEQ = [3, 1]
+def neq_of(be):
+    """equations per node of the two residuals: u has ndims (3, or 2 on tri3 meshes), p has 1"""
+    return [getattr(be, "ndims", 3), 1]
 
 
 def block_matrix(be, ls):
     n = be.nnodes
+    NEQ = neq_of(be)
     blocks = [[None, None], [None, None]]
     for i in range(2):
         for j in range(2):
@@ -50,6 +53,7 @@ class Tbc:
 def apply_dbcs(be, ls, dbcs, x, coords, t, is_adjoint=False):
     """dbcs.cpp:28-121: keep the diagonal, zero the rest of the row in every block,
     R[row] = diag * (sol - v) (0 for the adjoint system)."""
+    NEQ = neq_of(be)
     for bc in dbcs:
         i = bc.resid
         for node in bc.nodes:
@@ -126,7 +130,7 @@ class Primal:
         self.step_size = step_size
         self.use_line_search = use_line_search
         n = be.nnodes
-        self.u = [np.zeros(n * 3)]
+        self.u = [np.zeros(n * neq_of(be)[0])]
         self.p = [np.zeros(n)]
         self.xi = [be.new_state()]
         self.ls = be.new_linsys()
@@ -149,7 +153,7 @@ class Primal:
         assert len(self.u) == step
         x = [self.u[step - 1].copy(), self.p[step - 1].copy()]
         xi = self.xi[step - 1].copy()
-        n3 = be.nnodes * 3
+        n3 = be.nnodes * neq_of(be)[0]
         it, converged, r0 = 1, False, 1.0
         while it <= self.max_iters and not converged:
             if self._assemble(step, x, xi) != 0:
@@ -218,11 +222,11 @@ def adjoint_gradient(primal, nparams):
     """adjoint_objective.cpp:83-95 + adjoint.cpp:76-189: march backwards, return dJ/dp."""
     be = primal.be
     nsteps = len(primal.u) - 1
-    nd = 4 * be.nn
+    nd = (neq_of(be)[0] + 1) * be.nn
     g = np.zeros((be.nelems, be.npts, be.nloc))
     f = np.zeros((be.nelems, be.npts, nd))
     grad = np.zeros(nparams)
-    n3 = be.nnodes * 3
+    n3 = be.nnodes * neq_of(be)[0]
     ls = be.new_linsys()
     for step in range(nsteps, 0, -1):
         u, p, xi = primal.u[step], primal.p[step], primal.xi[step]

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libc8oracle.so")
 
-TET4, HEX8 = 4, 8
+TRI3, TET4, HEX8 = 3, 4, 8
 NUM_PARAMS = {"elastic": 4, "small_J2": 6, "hyper_J2": 8}
 
 _lib = None
@@ -40,6 +40,7 @@ def lib():
                                  C.c_int, C.c_double, C.c_double, dp, C.c_int, C.c_int, ip]
         L.c8o_destroy.argtypes = [C.c_void_p]
         L.c8o_nloc.argtypes = [C.c_void_p]
+        L.c8o_ndims.argtypes = [C.c_void_p]
         L.c8o_npts.argtypes = [C.c_void_p]
         L.c8o_set_params.argtypes = [C.c_void_p, dp]
         L.c8o_set_active.argtypes = [C.c_void_p, C.c_int, C.c_int, ip]
@@ -86,7 +87,7 @@ class LinSys:
 
     def __init__(self, oracle):
         self.A = [[np.zeros(oracle.nnz[i][j]) for j in range(2)] for i in range(2)]
-        self.b = [np.zeros(oracle.nnodes * 3), np.zeros(oracle.nnodes)]
+        self.b = [np.zeros(oracle.nnodes * getattr(oracle, "ndims", 3)), np.zeros(oracle.nnodes)]
 
     def zero(self):
         for i in range(2):
@@ -122,12 +123,13 @@ class Oracle:
             raise RuntimeError("c8o_create failed")
         self.nloc = L.c8o_nloc(self.h)
         self.npts = L.c8o_npts(self.h)
+        self.ndims = L.c8o_ndims(self.h)  # 3, or 2 for tri3 (u has ndims equations per node; coords stay [n][3])
         self.nn = self.conn.shape[1]
-        self.ndofs = 4 * self.nn
+        self.ndofs = (self.ndims + 1) * self.nn
         self.nnz = [[L.c8o_graph_nnz(self.h, i, j) for j in range(2)] for i in range(2)]
         self.rowptr = [[None, None], [None, None]]
         self.colidx = [[None, None], [None, None]]
-        neq = [3, 1]
+        neq = [self.ndims, 1]
         for i in range(2):
             for j in range(2):
                 rp = np.zeros(self.nnodes * neq[i] + 1, dtype=np.int64)

@@ -161,6 +161,28 @@ def test_adjoint_gradient_fd_check_small_J2():
     assert errs.min() < 1e-7 * abs(gd), (errs.min(), gd)
 
 
+def canonical_fd_drop(solve, adjoint_gradient_fn, p0, bounds):
+    """The reference's gradient check (main_inverse.cpp:126-158: ROL checkGradient, 13 steps 1e0 .. 1e-12, order 2 =
+    central differences, direction 0.1 in every CANONICAL variable c = (p - mean) / span of objective.cpp:41-61):
+    log10(max |error| / min |error|) over the 13 steps.  solve(params) -> solved Primal; bounds {param index: (lo, hi)}."""
+    idx = sorted(bounds)
+    span = np.array([0.5 * (bounds[k][1] - bounds[k][0]) for k in idx])
+    pr = solve(p0)
+    grad_canonical = adjoint_gradient_fn(pr, len(idx)) * span  # objective.cpp:125-137
+    d = np.full(len(idx), 0.1)
+    gd = float(grad_canonical @ d)
+    errs = []
+    for k in range(13):
+        h = 10.0 ** (-k)
+        pp, pm = np.array(p0, dtype=float), np.array(p0, dtype=float)
+        pp[idx] += h * d * span
+        pm[idx] -= h * d * span
+        fd = (solve(pp).qoi() - solve(pm).qoi()) / (2 * h)
+        errs.append(abs(fd - gd))
+    errs = np.array(errs)
+    return float(np.log10(errs.max() / errs.min()))
+
+
 def calibration_bar(params, measured=None, nsteps=3, kind="hex8"):
     """A bar pulled in y: displacement mismatch on the xmax face, reaction load on the ymin plane (component y)."""
     c, conn, sets = brick(2, 3, 2, 1.0, 1.5, 1.0)

@@ -121,6 +121,69 @@ def test_notch_hypo_J2_deck_is_hypo_hill(notch):
     assert pr.xi[-1][:, :, 6].max() > 1e-2
 
 
+@pytest.fixture(scope="module")
+def notch2d():
+    d = json.load(open(os.path.join(HERE, "golden", "notch2D_tri3.json")))
+    d["coords"] = np.array(d["coords"], dtype=np.float64)
+    d["conn"] = np.array(d["conn"], dtype=np.int32)
+    return d
+
+
+def notch2d_dbcs(m, rate):
+    ns = m["node_sets"]
+    return [Dbc(0, 0, ns["xmin"], lambda x, y, z, t: 0.0), Dbc(0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            Dbc(0, 1, ns["ymax"], lambda x, y, z, t: rate * t)]
+
+
+def test_notch2D_small_J2(notch2d):
+    # primal/notch2D_small_J2.yaml.in: THE deck that runs the model named small_J2 (the bench model): 447 tri3,
+    # `mechanics` with 2 + 1 equations per node, small_J2 on 2 x 2 tensors (E 1000 nu 0.25 K 100 Y 10, :21-33),
+    # 8 steps, ymax pulled by 0.001 t (:36-40); pin :45-46, deck tolerance 1e-4
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "small_J2", [1000.0, 0.25, 100.0, 10.0, 0.0, 0.0],
+                   max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    assert be.ndims == 2 and be.nloc == 4 and be.npts == 1 and be.ndofs == 9
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.001), max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(8)
+    # Deck tolerance 1e-4; measured 1.16e-5.  This pin is one of the reference's OLDER values (18 digits, like the cube
+    # pins, which the oracle meets to 1e-8 .. 1e-13); the decks whose values were regenerated with the current sources
+    # (17 digits) are met to 1e-12 or better -- among them notch2D_small_J2_plane_strain below, which shares the mesh,
+    # the 2-D `mechanics` residual, the stabilisation, the node sets and the objective with this deck and differs only
+    # in the local model.  The objective is sensitive to the pressure stabilisation (1 % of tau moves it by 3.7e-5).
+    assert rel(pr.qoi(), 6.55208497250819866e-03) < 2.0e-5, pr.qoi()
+    assert pr.xi[-1][:, :, 3].max() > 1e-3  # the notch root has yielded (alpha is local unknown 3 in 2-D)
+
+
+def test_notch2D_small_J2_plane_strain_deck_is_small_hill_plane_strain(notch2d):
+    # primal/notch2D_small_J2_plane_strain.yaml.in: the same mesh, `mechanics` in 2-D and boundary conditions with
+    # `small_hill_plane_strain` (:21; R = 1, Voce Y 2 S 10 D 2), 4 steps, Newton 30 iterations; pin :47-48
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "small_hill_plane_strain",
+                   [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.001), max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 1.7664579853744898e-03) < 1.0e-10, pr.qoi()  # deck tolerance 1e-4; measured 8.6e-13
+    assert pr.xi[-1][:, :, 3].max() > 1e-2
+
+
+def test_notch2D_small_J2_adjoint_gradient_check(notch2d):
+    # adjoint/notch2D_small_J2_adjoint_check.yaml.in: Y 2, 4 steps, tolerances 1e-12, parameters E nu K Y active;
+    # the reference runs ROL's checkGradient (13 steps 1e0 .. 1e-12, second-order differences, direction = 0.1 in the
+    # canonical variables, main_inverse.cpp:126-158) and pins log10(max error / min error) = 7.738 +- 10 % (:39-40):
+    # its floor is the 1e-6 GMRES tolerance.  With direct solves the same recipe bottoms out lower; the gradient is
+    # right if the drop is AT LEAST the reference's.
+    from fe_driver import adjoint_gradient
+    from test_oracle_checks import canonical_fd_drop
+    p0 = np.array([1000.0, 0.25, 100.0, 2.0, 0.0, 0.0])
+    bounds = {0: (800.0, 1000.0), 1: (0.2, 0.3), 2: (90.0, 110.0), 3: (1.0, 3.0)}
+
+    def solve(params):
+        be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "small_J2", list(params), max_iters=500,
+                       abs_tol=1e-12, rel_tol=1e-12)
+        be.set_active(0, [0, 1, 2, 3])
+        return Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.001), max_iters=15, abs_tol=1e-12,
+                      rel_tol=1e-12).solve(4)
+
+    drop = canonical_fd_drop(solve, adjoint_gradient, p0, bounds)
+    assert drop > 0.9 * 7.7384790056517998, drop
+
+
 def test_baseline_config1_hex8_elastic_bar():
     # BASELINE.json configs[0] (SURVEY.md 8d "Config 1 (plumbing)"): 10 x 10 x 10 hex8 unit bar, `elastic` with the
     # material of cube_elastic.yaml.in:21-27, symmetric BCs on xmin/ymin/zmin: free thermal expansion,
