@@ -94,23 +94,25 @@ template <class E, class R, class SH> C8_HD void commit_cached_shape(R const& r,
   if (lane == E::NP0) sh.h = r.sx;
 }
 
-template <class E, int NL> struct WaveShared {
+// ADJ / PREV: the arrays only the adjoint assembly / only finite-deformation models use are left out of the other
+// instantiations (one entry instead): 17.7 KB instead of 19.2 KB for the forward assembly of a small-strain model.
+template <class E, int NL, bool ADJ = true, bool PREV = true> struct WaveShared {
   static constexpr int NLP = 8;  // lanes per point in phase N
   double X[E::NN][3];
   double u[E::NN][3], p[E::NN];
-  double u_prev[E::NN][3];
+  double u_prev[PREV ? E::NN : 1][3];
   double N[E::NP0][E::NN];
   double dN[E::NP0][E::NN][3];
   double wdv[E::NP0];
   double M[E::NP0][NLP][NLP + 1];   // dC/dxi per point
   double q[E::NP0][WQ];             // interpolated values
-  double qprev[E::NP0][9];          // grad_u at the previous step (finite deformation)
+  double qprev[PREV ? E::NP0 : 1][9];  // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
   double xip[E::NP0][NLP];          // previous local state
   double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
   double F[E::NP0][WQ];             // flux values
-  double gh[E::NP0][NLP];           // adjoint: local history g at each point
-  double rq[4][WQ + 1];             // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
+  double gh[ADJ ? E::NP0 : 1][NLP]; // adjoint: local history g at each point
+  double rq[ADJ ? 4 : 1][WQ + 1];   // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
   double h;
   int32_t node[E::NN];
   int32_t nptr[E::NN], deg[E::NN];
@@ -375,8 +377,8 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
 // ADJOINT = true : eval_adjoint_jacobian (evaluations.cpp:349-526): no local solve (stored xi), the element
 //                  matrix is scattered transposed, and the right-hand side is -dJ/dx + f + (dxi/dx)^T g with
 //                  g -= dJ/dxi updated in place; every x-derivative goes through the point quantities q.
-template <class E, template <class> class ModelT, class QoI, bool ADJOINT, class EX>
-C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt, ModelSettings const& ms,
+template <class E, template <class> class ModelT, class QoI, bool ADJOINT, class EX, class SH>
+C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings const& ms,
                          FieldArgs const& fa, AdjointArgs const& aa, SystemArgs const& sa, int e) {
   using Model = ModelT<Dual>;
   constexpr int NL = Model::NLOC;
@@ -773,7 +775,10 @@ C8_HD void jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTabl
 // row) and then adds the finished rows to the four CSR blocks and the node's residual entries to b with
 // contiguous accesses.
 template <class E, int MAXDEG> struct GatherShared {
-  double acc[MAXDEG][16];
+  // one double of padding per accumulator row: 80 % of the LDS cycles of the unpadded form were bank conflicts; it is
+  // worth 0.6 % of an assembly (the kernel waits on HBM, not on LDS)
+  static constexpr int LD = 17;
+  double acc[MAXDEG][LD];
 };
 
 template <class E, int MAXDEG> struct GatherLane {
@@ -791,6 +796,11 @@ template <class E, int MAXDEG> struct GatherLane {
   double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
   double rsum;
 };
+
+// value index (row, column of the node's 4 x NDOF block) of load j of a lane
+template <int NLD> C8_HD int gather_idx(int lane, int j) {
+  return NLD == 2 ? 2 * lane + j : lane + 64 * j;  // two values per lane: adjacent, fetched by one 16-byte load
+}
 
 template <class E, int MAXDEG, class EX>
 C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs const& ga, int node) {
@@ -820,10 +830,11 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
     }
     r.a11 = 0.;
     if (!ga.assign && lane < deg) r.a11 = ga.A[1][1][np + lane];
+    constexpr int LDA = GatherShared<E, MAXDEG>::LD;
     C8_UNROLL
-    for (int it = 0; it < MAXDEG / 4; ++it) {
+    for (int it = 0; it < (MAXDEG * LDA + 63) / 64; ++it) {
       int const q = lane + 64 * it;
-      if (q < deg * 16) (&sh.acc[0][0])[q] = 0.;
+      if (q < deg * LDA) (&sh.acc[0][0])[q] = 0.;
     }
     r.rsum = 0.;
   });
@@ -840,14 +851,18 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
           double const* const st = ga.stage + (size_t)(e % ga.stage_ring) * stage_stride<E>();
           C8_UNROLL
           for (int j = 0; j < NLD; ++j) {
-            int const idx = lane + 64 * j;  // (row rr, column c) of the node's block: idx = rr * NDOF + c
+            int const idx = gather_idx<NLD>(lane, j);  // (row rr, column c) of the node's block: idx = rr * NDOF + c
             r.pos[k][j] = -1;
             if (idx < NB) {
               int const c = idx % E::NDOF;
               int const m = c < 3 * E::NN ? c / 3 : c - 3 * E::NN;
               r.pos[k][j] = ga.pos[((size_t)e * E::NN + m) * E::NN + ln];
-              r.v[k][j] = C8_STREAM_LOAD(st + stage_row<E>(ln, 0) + idx);
             }
+          }
+          if (NLD == 2) {  // one 16-byte load: values 2 lane and 2 lane + 1 (two 8-byte loads per lane: +2 % per assembly)
+            C8_STREAM_LOAD2(st + stage_row<E>(ln, 0) + 2 * lane, r.v[k][0], r.v[k][NLD - 1]);
+          } else if (lane < NB) {
+            r.v[k][0] = C8_STREAM_LOAD(st + stage_row<E>(ln, 0) + lane);
           }
           r.rv[k] = (lane < 4) ? st[E::NN * 4 * E::NDOF + (lane < 3 ? 3 * ln + lane : 3 * E::NN + ln)] : 0.;
         }
@@ -860,7 +875,7 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
         auto& r = ex.lane(lane);
         C8_UNROLL
         for (int j = 0; j < NLD; ++j) {
-          int const idx = lane + 64 * j;
+          int const idx = gather_idx<NLD>(lane, j);
           if (idx < NB) {
             int const rr = idx / E::NDOF, c = idx % E::NDOF;
             int const col = c < 3 * E::NN ? c % 3 : 3;
@@ -899,14 +914,14 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
   ex.sync();
 }
 
-template <class E, template <class> class ModelT, class EX>
-C8_HD void forward_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
+template <class E, template <class> class ModelT, class EX, class SH>
+C8_HD void forward_jacobian_wave(EX& ex, SH& sh, MeshTables const& mt,
                                  ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
   jacobian_wave<E, ModelT, PointQoi, false>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
 }
 
-template <class E, template <class> class ModelT, class QoI, class EX>
-C8_HD void adjoint_jacobian_wave(EX& ex, WaveShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
+template <class E, template <class> class ModelT, class QoI, class EX, class SH>
+C8_HD void adjoint_jacobian_wave(EX& ex, SH& sh, MeshTables const& mt,
                                  ModelSettings const& ms, FieldArgs const& fa, AdjointArgs const& aa,
                                  SystemArgs const& sa, int e) {
   jacobian_wave<E, ModelT, QoI, true>(ex, sh, mt, ms, fa, aa, sa, e);

@@ -129,7 +129,7 @@ k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArg
                                                                int first, int count, int nblocks) {
   constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLane<ModelT>;
-  __shared__ WaveShared<E, ModelT<Dual>::NLOC> shs[WPB];
+  __shared__ WaveShared<E, ModelT<Dual>::NLOC, false, ModelT<Dual>::FINITE_DEF> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -158,7 +158,7 @@ k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointAr
                                                                   SystemArgs sa, int first, int count, int nblocks) {
   constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLane<ModelT>;
-  __shared__ WaveShared<E, ModelT<Dual>::NLOC> shs[WPB];
+  __shared__ WaveShared<E, ModelT<Dual>::NLOC, true, ModelT<Dual>::FINITE_DEF> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -26,9 +26,18 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define C8_STREAM_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #define C8_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+// two adjacent doubles (16-byte aligned) with one 16-byte load
+#define C8_STREAM_LOAD2(p, a, b)                                                        \
+  do {                                                                                  \
+    typedef double c8_d2 __attribute__((ext_vector_type(2)));                           \
+    c8_d2 const w__ = __builtin_nontemporal_load(reinterpret_cast<c8_d2 const*>(p));    \
+    (a) = w__.x;                                                                        \
+    (b) = w__.y;                                                                        \
+  } while (0)
 #else
 #define C8_STREAM_STORE(p, v) (*(p) = (v))
 #define C8_STREAM_LOAD(p) (*(p))
+#define C8_STREAM_LOAD2(p, a, b) do { (a) = (p)[0]; (b) = (p)[1]; } while (0)
 #endif
 #if defined(__clang__)
 #define C8_UNROLL _Pragma("unroll")

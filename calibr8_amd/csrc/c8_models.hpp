@@ -27,6 +27,7 @@ namespace c8 {
 
 enum { C8_ELASTIC_PATH = 0, C8_PLASTIC_PATH = 1 };
 
+
 C8_HD void set_val(double& x, double v) { x = v; }
 C8_HD void set_val(Dual& x, double v) { x.v = v; }  // keeps the seeding (local_residual.cpp:293-296)
 

@@ -166,8 +166,7 @@ def test_notch2D_small_J2_adjoint_gradient_check(notch2d):
     # adjoint/notch2D_small_J2_adjoint_check.yaml.in: Y 2, 4 steps, tolerances 1e-12, parameters E nu K Y active;
     # the reference runs ROL's checkGradient (13 steps 1e0 .. 1e-12, second-order differences, direction = 0.1 in the
     # canonical variables, main_inverse.cpp:126-158) and pins log10(max error / min error) = 7.738 +- 10 % (:39-40):
-    # its floor is the 1e-6 GMRES tolerance.  With direct solves the same recipe bottoms out lower; the gradient is
-    # right if the drop is AT LEAST the reference's.
+    # the same recipe here (direct linear solves) gives 7.37, inside the deck's band.
     from fe_driver import adjoint_gradient
     from test_oracle_checks import canonical_fd_drop
     p0 = np.array([1000.0, 0.25, 100.0, 2.0, 0.0, 0.0])
@@ -181,7 +180,7 @@ def test_notch2D_small_J2_adjoint_gradient_check(notch2d):
                       rel_tol=1e-12).solve(4)
 
     drop = canonical_fd_drop(solve, adjoint_gradient, p0, bounds)
-    assert drop > 0.9 * 7.7384790056517998, drop
+    assert abs(drop - 7.7384790056517998) / 7.7384790056517998 < 0.1, drop  # the deck's own criterion; measured 7.372
 
 
 def test_baseline_config1_hex8_elastic_bar():
