@@ -39,7 +39,7 @@ class LinearSystem:
         import torch
         # one allocation, the six arrays are views of it: zero_all is one fill and the halo exchange packs and
         # unpacks all of them with one gather / one index_add (distributed.Halo.start_gather)
-        sizes = [asm.nnz[i][j] for i in range(2) for j in range(2)] + [asm.nnodes * NEQ[i] for i in range(2)]
+        sizes = [asm.nnz[i][j] for i in range(2) for j in range(2)] + [asm.nnodes * asm.neq[i] for i in range(2)]
         self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)  # A00 A01 A10 A11 b0 b1
         self.flat = torch.zeros(int(self.offsets[-1]), dtype=torch.float64, device=asm.device)
         v = [self.flat[int(self.offsets[k]):int(self.offsets[k + 1])] for k in range(6)]
@@ -91,7 +91,9 @@ class Assembler:
         self.nloc = self.L.c8_num_local_dofs(h)
         self.npts = self.L.c8_num_local_points(h)
         self.ncolors = self.L.c8_num_colors(h)
-        self.ndofs = 4 * self.nn
+        self.ndims = self.L.c8_num_dims(h)  # 3, or 2 on tri3 meshes (u arrays are [nnodes * ndims])
+        self.neq = (self.ndims, 1)
+        self.ndofs = (self.ndims + 1) * self.nn
         self.nnz = [[int(self.L.c8_graph_nnz(h, i, j)) for j in range(2)] for i in range(2)]
         self._graph = None
         if scatter is not None:  # None: the library's default (staged assembly, see c8_set_scatter_mode)
@@ -112,7 +114,7 @@ class Assembler:
             ci = [[None, None], [None, None]]
             for i in range(2):
                 for j in range(2):
-                    r = np.zeros(self.nnodes * NEQ[i] + 1, dtype=np.int64)
+                    r = np.zeros(self.nnodes * self.neq[i] + 1, dtype=np.int64)
                     c = np.zeros(self.nnz[i][j], dtype=np.int32)
                     _l.check(self.L.c8_graph(self.h, i, j, r.ctypes.data_as(_l.i64p), c.ctypes.data_as(_l.i32p)))
                     rp[i][j], ci[i][j] = r, c

@@ -37,8 +37,13 @@ template <class T> static int upload(T** dptr, std::vector<T> const& h) {
   return C8_OK;
 }
 
-static int model_id(char const* name, int* nloc, int* nparams) {
+static int model_id(char const* name, int ndims, int* nloc, int* nparams) {
   std::string const s = name ? name : "";
+  if (ndims == 2) {  // the models of the reference's 2-D decks that run on `mechanics` (2 + 1 equations per node)
+    if (s == "small_J2") { *nloc = SmallJ2Plane<double>::NLOC; *nparams = SmallJ2Plane<double>::NPARAMS; return MODEL_SMALL_J2; }
+    if (s == "small_hill_plane_strain") { *nloc = SmallHillPlaneStrain<double>::NLOC; *nparams = SmallHillPlaneStrain<double>::NPARAMS; return MODEL_SMALL_HILL_PLANE_STRAIN; }
+    return MODEL_NONE;
+  }
   if (s == "elastic") { *nloc = Elastic<double>::NLOC; *nparams = Elastic<double>::NPARAMS; return MODEL_ELASTIC; }
   if (s == "small_J2") { *nloc = SmallJ2<double>::NLOC; *nparams = SmallJ2<double>::NPARAMS; return MODEL_SMALL_J2; }
   if (s == "hyper_J2") { *nloc = HyperJ2<double>::NLOC; *nparams = HyperJ2<double>::NPARAMS; return MODEL_HYPER_J2; }
@@ -79,15 +84,16 @@ const char* c8_build_info(void) { return "id=" C8_BUILD_ID " flags=" C8_BUILD_FL
 int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   if (!md || !mo || !out) return fail(C8_ERR_ARG, "c8_create: null argument");
   *out = nullptr;
-  if (md->elem_type != C8_ELEM_TET4 && md->elem_type != C8_ELEM_HEX8)
-    return fail(C8_ERR_UNSUPPORTED, "c8_create: elem_type must be C8_ELEM_TET4 or C8_ELEM_HEX8");
+  if (md->elem_type != C8_ELEM_TET4 && md->elem_type != C8_ELEM_HEX8 && md->elem_type != C8_ELEM_TRI3)
+    return fail(C8_ERR_UNSUPPORTED, "c8_create: elem_type must be C8_ELEM_TRI3, C8_ELEM_TET4 or C8_ELEM_HEX8");
+  int const ndims = md->elem_type == C8_ELEM_TRI3 ? 2 : 3;
   if (md->num_nodes <= 0 || md->num_elems <= 0 || md->num_elem_sets <= 0 || !md->coords || !md->conn)
     return fail(C8_ERR_ARG, "c8_create: empty mesh");
   if (std::string(mo->global_type ? mo->global_type : "") != "mechanics")
     return fail(C8_ERR_UNSUPPORTED, "c8_create: global residual must be 'mechanics' (mixed formulation)");
   int nloc = 0, nparams = 0;
-  int const model = model_id(mo->local_type, &nloc, &nparams);
-  if (model == MODEL_NONE) return fail(C8_ERR_UNSUPPORTED, std::string("c8_create: unknown local residual name: ") + (mo->local_type ? mo->local_type : "(null)"));
+  int const model = model_id(mo->local_type, ndims, &nloc, &nparams);
+  if (model == MODEL_NONE) return fail(C8_ERR_UNSUPPORTED, std::string("c8_create: unknown local residual name") + (ndims == 2 ? " for a 2-D mesh: " : ": ") + (mo->local_type ? mo->local_type : "(null)"));
   if (mo->num_params != nparams || !mo->params) return fail(C8_ERR_ARG, "c8_create: wrong number of material parameters for this model");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -95,7 +101,8 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
 
   c8_ctx* c = new c8_ctx();
   c->mesh.elem_type = md->elem_type;
-  c->mesh.nn = md->elem_type;
+  c->ndims = ndims;
+  c->mesh.nn = md->elem_type;  // 3, 4, 8: the type ids are the node counts
   c->mesh.nnodes = md->num_nodes;
   c->mesh.nelems = md->num_elems;
   c->mesh.nsets = md->num_elem_sets;
@@ -119,7 +126,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   c->model = model;
   c->nloc = nloc;
   c->nparams = nparams;
-  c->npts0 = (md->elem_type == C8_ELEM_HEX8) ? Elem<C8_HEX8>::NP0 : Elem<C8_TET4>::NP0;
+  c->npts0 = (md->elem_type == C8_ELEM_HEX8) ? Elem<C8_HEX8>::NP0 : (md->elem_type == C8_ELEM_TET4 ? Elem<C8_TET4>::NP0 : Elem<C8_TRI3>::NP0);
   c->ms = ModelSettings{mo->stabilization_multiplier, mo->local_abs_tol, mo->local_rel_tol, mo->local_max_iters};
   c->params.assign(mo->params, mo->params + (size_t)md->num_elem_sets * nparams);
   c->active.assign(md->num_elem_sets, std::vector<int32_t>());
@@ -143,7 +150,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   // default scatter mode: the staged assembly (fastest, reproducible) where the node degrees allow it; its stage is
   // allocated at the first Jacobian assembly and, should that fail, the context falls back to colour batches
   c->scatter_auto = true;
-  c->scatter_mode = (c->graph.max_degree <= c8::GATHER_MAX_DEGREE) ? C8_SCATTER_GATHER : C8_SCATTER_COLORED;
+  c->scatter_mode = (c->ks.can_stage && c->graph.max_degree <= c8::GATHER_MAX_DEGREE) ? C8_SCATTER_GATHER : C8_SCATTER_COLORED;
   g_c8_last_error.clear();
   *out = c;
   return C8_OK;
@@ -184,15 +191,16 @@ void c8_destroy(c8_ctx* c) {
 }
 
 int c8_num_local_dofs(const c8_ctx* c) { return c ? c->nloc : C8_ERR_ARG; }
+int c8_num_dims(const c8_ctx* c) { return c ? c->ndims : C8_ERR_ARG; }
 int c8_num_local_points(const c8_ctx* c) { return c ? c->npts0 : C8_ERR_ARG; }
 int c8_num_colors(const c8_ctx* c) { return c ? (int)c->color_off.size() - 1 : C8_ERR_ARG; }
 int64_t c8_graph_nnz(const c8_ctx* c, int i, int j) {
   if (!c || i < 0 || i > 1 || j < 0 || j > 1) return C8_ERR_ARG;
-  return block_nnz(c->graph, c->mesh.nnodes, i, j);
+  return block_nnz(c->graph, c->mesh.nnodes, i, j, c->ndims);
 }
 int c8_graph(const c8_ctx* c, int i, int j, int64_t* rowptr, int32_t* colidx) {
   if (!c || i < 0 || i > 1 || j < 0 || j > 1 || !rowptr || !colidx) return fail(C8_ERR_ARG, "c8_graph: bad argument");
-  block_csr(c->graph, c->mesh.nnodes, i, j, rowptr, colidx);
+  block_csr(c->graph, c->mesh.nnodes, i, j, rowptr, colidx, c->ndims);
   return C8_OK;
 }
 int c8_init_variables(const c8_ctx* c, double* xi) {
@@ -202,7 +210,8 @@ int c8_init_variables(const c8_ctx* c, double* xi) {
     double* x = xi + q * c->nloc;
     switch (c->model) {  // init_variables_impl of each model
       case MODEL_ELASTIC: Elastic<double>::init_variables(x); break;
-      case MODEL_SMALL_J2: SmallJ2<double>::init_variables(x); break;
+      case MODEL_SMALL_J2: if (c->ndims == 2) SmallJ2Plane<double>::init_variables(x); else SmallJ2<double>::init_variables(x); break;
+      case MODEL_SMALL_HILL_PLANE_STRAIN: SmallHillPlaneStrain<double>::init_variables(x); break;
       case MODEL_HYPER_J2: HyperJ2<double>::init_variables(x); break;
       case MODEL_SMALL_HILL: SmallHill<double>::init_variables(x); break;
       case MODEL_ISOTROPIC_ELASTIC: IsotropicElastic<double>::init_variables(x); break;
@@ -242,6 +251,7 @@ int c8_set_stream(c8_ctx* c, void* s) {
 int c8_set_scatter_mode(c8_ctx* c, int mode) {
   if (!c || (mode != C8_SCATTER_ATOMIC && mode != C8_SCATTER_COLORED && mode != C8_SCATTER_GATHER)) return fail(C8_ERR_ARG, "c8_set_scatter_mode: bad argument");
   if (mode == C8_SCATTER_GATHER) {
+    if (!c->ks.can_stage) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: staged (gather) assembly is built for 3-D elements");
     if (c->graph.max_degree > c8::GATHER_MAX_DEGREE) return fail(C8_ERR_UNSUPPORTED, "c8_set_scatter_mode: node degree too large for staged (gather) assembly");
   }
   if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_scatter_mode: a staged assembly is waiting for c8_gather_finish");

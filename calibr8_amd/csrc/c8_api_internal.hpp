@@ -20,6 +20,7 @@ struct c8_ctx {
   std::vector<int32_t> order, color_off;
   int model = c8::MODEL_NONE;
   int nloc = 0, nparams = 0, npts0 = 0;
+  int ndims = 3;                      // 3, or 2 on tri3 meshes: u has ndims equations per node
   c8::ModelSettings ms{};
   std::vector<double> params;
   std::vector<std::vector<int32_t>> active;

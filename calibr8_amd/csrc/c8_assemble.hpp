@@ -140,6 +140,7 @@ template <class E, class SH> C8_HD void shape_entry(SH& sh, int ip_set, int pt, 
       C8_UNROLL
       for (int b = 0; b < 3; ++b) J[a][b] += g[a] * sh.X[n][b];
   }
+  if (E::DIM == 2) J[2][2] = 1.;  // 2-D: the in-plane 2 x 2 Jacobian, completed by the unit out-of-plane direction
   Tens3<double> Jt;
   Jt.xx = J[0][0]; Jt.xy = J[0][1]; Jt.xz = J[0][2];
   Jt.yx = J[1][0]; Jt.yy = J[1][1]; Jt.yz = J[1][2];
@@ -335,9 +336,14 @@ C8_HD void load_element(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& f
     int const node = mt.conn[e * E::NN + n];
     if (i == 0) {
       sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
-      sh.u[n][eq] = fa.u[(size_t)node * 3 + eq];
-      if (prev) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * 3 + eq];
+      sh.u[n][eq] = fa.u[(size_t)node * E::DIM + eq];
+      if (prev) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * E::DIM + eq];
     } else {
+      if (E::DIM == 2) {  // out-of-plane entries of the 3-wide containers
+        sh.X[n][2] = 0.;
+        sh.u[n][2] = 0.;
+        if (prev) sh.u_prev[n][2] = 0.;
+      }
       sh.p[n] = fa.p[node];
       sh.node[n] = node;
       if (mt.nodeptr) {
@@ -356,13 +362,14 @@ C8_HD void accumulate_coupled(SH const& sh, int pt, int k, MechFlux<Dual> const&
   double const wdv = sh.wdv[pt];
   int ik, nk, eqk;
   slot_to_dof<E>(k, ik, nk, eqk);
+  constexpr int D = E::DIM;
   C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double const d0 = sh.dN[pt][n][0] * wdv, d1 = sh.dN[pt][n][1] * wdv, d2 = sh.dN[pt][n][2] * wdv;
-    Jcol[3 * n + 0] += f.Gu.xx.d * d0 + f.Gu.xy.d * d1 + f.Gu.xz.d * d2;
-    Jcol[3 * n + 1] += f.Gu.yx.d * d0 + f.Gu.yy.d * d1 + f.Gu.yz.d * d2;
-    Jcol[3 * n + 2] += f.Gu.zx.d * d0 + f.Gu.zy.d * d1 + f.Gu.zz.d * d2;
-    Jcol[3 * E::NN + n] += f.Vp.d * (sh.N[pt][n] * wdv) + f.Gp[0].d * d0 + f.Gp[1].d * d1 + f.Gp[2].d * d2;
+    Jcol[D * n + 0] += f.Gu.xx.d * d0 + f.Gu.xy.d * d1 + f.Gu.xz.d * d2;
+    Jcol[D * n + 1] += f.Gu.yx.d * d0 + f.Gu.yy.d * d1 + f.Gu.yz.d * d2;
+    if (D == 3) Jcol[D * n + 2] += f.Gu.zx.d * d0 + f.Gu.zy.d * d1 + f.Gu.zz.d * d2;
+    Jcol[D * E::NN + n] += f.Vp.d * (sh.N[pt][n] * wdv) + f.Gp[0].d * d0 + f.Gp[1].d * d1 + f.Gp[2].d * d2;
   }
   double const d0 = sh.dN[pt][nk][0] * wdv, d1 = sh.dN[pt][nk][1] * wdv, d2 = sh.dN[pt][nk][2] * wdv;
   double const r0 = f.Gu.xx.v * d0 + f.Gu.xy.v * d1 + f.Gu.xz.v * d2;
@@ -398,13 +405,13 @@ C8_HD void scatter_lhs(EX& ex, SH const& sh, MeshTables const& mt, SystemArgs co
     double const* Jc = getj(k);
     int ik, nk, eqk;
     slot_to_dof<E>(k, ik, nk, eqk);
-    int const neqk = ik == 0 ? 3 : 1;
+    int const neqk = ik == 0 ? E::DIM : 1;
     uint8_t const* posk = mt.pos + ((size_t)e * E::NN + nk) * E::NN;  // pos[e][col node nk][row node]
     C8_UNROLL
     for (int a = 0; a < E::NDOF; ++a) {
       int ia, na, eqa;
       slot_to_dof<E>(a, ia, na, eqa);
-      int const neqa = ia == 0 ? 3 : 1;
+      int const neqa = ia == 0 ? E::DIM : 1;
       size_t off;
       double* vals;
       if (!transpose) {  // entry (row a, col k)
@@ -429,7 +436,7 @@ C8_HD void scatter_rhs(EX& ex, SH const& sh, SystemArgs const& sa, GetR getr, in
   ex.each([&](int k) {
     int ik, nk, eqk;
     slot_to_dof<E>(k, ik, nk, eqk);
-    int const neqk = ik == 0 ? 3 : 1;
+    int const neqk = ik == 0 ? E::DIM : 1;
     ex.add(sa.b[ik] + (size_t)sh.node[nk] * neqk + eqk, getr(k), sa.atomic);
   });
 }
@@ -555,7 +562,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           int ik, nk, eqk;
           slot_to_dof<E>(k, ik, nk, eqk);
           C8_UNROLL
-          for (int n = 0; n < E::NN; ++n) r.Jcol[3 * E::NN + n] += Vp.d * (sh.N[pt][n] * wdv);
+          for (int n = 0; n < E::NN; ++n) r.Jcol[E::DIM * E::NN + n] += Vp.d * (sh.N[pt][n] * wdv);
           if (ik == 1) r.Rk += Vp.v * (sh.N[pt][nk] * wdv);
         });
       }

@@ -37,12 +37,12 @@ C8_HD double flux_dot_adjoint(SH const& sh, int pt, MechFlux<Dual> const& f, boo
   C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double const d0 = sh.dN[pt][n][0], d1 = sh.dN[pt][n][1], d2 = sh.dN[pt][n][2];
-    double const zp = sh.z[3 * E::NN + n];
+    double const zp = sh.z[E::DIM * E::NN + n];
     zpv += zp * sh.N[pt][n];
     zpg[0] += zp * d0; zpg[1] += zp * d1; zpg[2] += zp * d2;
     C8_UNROLL
-    for (int i = 0; i < 3; ++i) {
-      double const zu = sh.z[3 * n + i];
+    for (int i = 0; i < E::DIM; ++i) {
+      double const zu = sh.z[E::DIM * n + i];
       zg[i][0] += zu * d0; zg[i][1] += zu * d1; zg[i][2] += zu * d2;
     }
   }
@@ -61,7 +61,7 @@ C8_HD void load_adjoint(EX& ex, SH& sh, AdjointArgs const& aa) {
   ex.each([&](int k) {
     int ik, nk, eqk;
     slot_to_dof<E>(k, ik, nk, eqk);
-    sh.z[k] = (ik == 0) ? aa.z_u[(size_t)sh.node[nk] * 3 + eqk] : aa.z_p[sh.node[nk]];
+    sh.z[k] = (ik == 0) ? aa.z_u[(size_t)sh.node[nk] * E::DIM + eqk] : aa.z_p[sh.node[nk]];
   });
   ex.sync();
 }
@@ -228,7 +228,7 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           Dual const Vp = Mechanics::flux_pressure(r.m, r.g);
           double const wdv = sh.wdv[pt];
           C8_UNROLL
-          for (int n = 0; n < E::NN; ++n) r.Jcol[3 * E::NN + n] += Vp.d * (sh.N[pt][n] * wdv);
+          for (int n = 0; n < E::NN; ++n) r.Jcol[E::DIM * E::NN + n] += Vp.d * (sh.N[pt][n] * wdv);
         });
       }
     }

@@ -4,19 +4,22 @@
 // evaluations.cpp:82-85 getIntPoint/getIntWeight/getDV) for tet4 -- the element
 // the reference runs (disc.cpp:165) -- and extends it to hex8 (BASELINE.json).
 // Element DOF order is residual-major, node-minor (global_residual.cpp:21-23):
-// slot = offset[i] + node*neq[i] + eq with residual 0 = u (3 eqs), 1 = p (1 eq).
+// slot = offset[i] + node*neq[i] + eq with residual 0 = u (DIM eqs), 1 = p (1 eq).
+// tri3 is the reference's 2-D element (disc.cpp:165): DIM = 2; nodal coordinates stay [n][3] (z = 0), point
+// quantities stay 3 x 3 containers whose out-of-plane entries are zero.
 #pragma once
 
 #include "c8_math.hpp"
 
 namespace c8 {
 
-enum { C8_TET4 = 4, C8_HEX8 = 8 };
+enum { C8_TRI3 = 3, C8_TET4 = 4, C8_HEX8 = 8 };
 
 template <int ET> struct Elem;
 
 template <> struct Elem<C8_HEX8> {
   static constexpr int TYPE = C8_HEX8;
+  static constexpr int DIM = 3;
   static constexpr int NN = 8;         // nodes
   static constexpr int NDOF = 32;      // 3*NN + NN
   static constexpr int NP0 = 8;        // coupled points (ip set 0): 2x2x2 Gauss
@@ -58,6 +61,7 @@ template <> struct Elem<C8_HEX8> {
 
 template <> struct Elem<C8_TET4> {
   static constexpr int TYPE = C8_TET4;
+  static constexpr int DIM = 3;
   static constexpr int NN = 4;
   static constexpr int NDOF = 16;
   static constexpr int NP0 = 1;        // order 1 (mechanics.cpp:45)
@@ -91,10 +95,40 @@ template <> struct Elem<C8_TET4> {
   }
 };
 
+template <> struct Elem<C8_TRI3> {
+  static constexpr int TYPE = C8_TRI3;
+  static constexpr int DIM = 2;
+  static constexpr int NN = 3;
+  static constexpr int NDOF = 9;       // 2*NN + NN
+  static constexpr int NP0 = 1;        // order 1 (mechanics.cpp:45): centroid
+  static constexpr int NP1 = 3;        // order 2 (mechanics.cpp:46): three interior points
+  static constexpr bool SAME_POINTS = false;
+  static constexpr int NEDGES = 3;
+  C8_HD static void point(int ip_set, int pt, double* xi, double& w) {
+    xi[2] = 0.;
+    if (ip_set == 0) {
+      xi[0] = xi[1] = 1. / 3.;
+      w = 0.5;
+    } else {
+      double const a = 1. / 6., b = 2. / 3.;
+      xi[0] = (pt == 0) ? b : a;
+      xi[1] = (pt == 1) ? b : a;
+      w = 1. / 6.;
+    }
+  }
+  C8_HD static double N(int n, double const* xi) { return n == 0 ? 1. - xi[0] - xi[1] : (n == 1 ? xi[0] : xi[1]); }
+  C8_HD static void dNdxi(int n, double const*, double* g) {
+    g[0] = (n == 0) ? -1. : (n == 1 ? 1. : 0.);
+    g[1] = (n == 0) ? -1. : (n == 2 ? 1. : 0.);
+    g[2] = 0.;
+  }
+  C8_HD static void edge(int e, int& a, int& b) { a = e; b = (e + 1) % 3; }  // (0,1)(1,2)(2,0)
+};
+
 // which residual / node / equation an element DOF slot addresses (dx_idx inverse)
 template <class E> C8_HD void slot_to_dof(int k, int& i, int& n, int& eq) {
-  if (k < 3 * E::NN) { i = 0; n = k / 3; eq = k - 3 * n; }
-  else { i = 1; n = k - 3 * E::NN; eq = 0; }
+  if (k < E::DIM * E::NN) { i = 0; n = k / E::DIM; eq = k - E::DIM * n; }
+  else { i = 1; n = k - E::DIM * E::NN; eq = 0; }
 }
 
 }  // namespace c8

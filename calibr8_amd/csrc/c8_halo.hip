@@ -488,6 +488,7 @@ int c8_halo_attach(c8_halo* h, c8_ctx* c, c8_comm* cm) {
   if (h->ctx) return c8_fail(C8_ERR_ARG, "c8_halo_attach: already attached");
   if (cm->rank != h->rank || cm->nranks != h->nranks) return c8_fail(C8_ERR_ARG, "c8_halo_attach: communicator rank / size differ from the halo's");
   if (c->mesh.nnodes != h->nnodes) return c8_fail(C8_ERR_ARG, "c8_halo_attach: the context has another number of nodes");
+  if (c->ndims != 3) return c8_fail(C8_ERR_UNSUPPORTED, "c8_halo_attach: the exchange tables are built for 3 + 1 equations per node (3-D meshes)");
   for (int32_t n = 0; n <= h->nnodes; ++n)
     if ((int64_t)c->graph.nodeptr[n] != h->nodeptr[n]) return c8_fail(C8_ERR_ARG, "c8_halo_attach: the context's graph is not the one the tables were built from");
   int rc;

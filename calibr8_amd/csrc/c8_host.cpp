@@ -102,14 +102,15 @@ void plan_staged_assembly(HostMesh const& m, HostGraph const& g, int min_chunk, 
     if (last[n] >= 0) plan.node_order[(size_t)fill[last[n] / plan.chunk]++] = n;
 }
 
-static int const NEQ[2] = {3, 1};
 
-int64_t block_nnz(HostGraph const& g, int nnodes, int i, int j) {
-  return (int64_t)g.nodeptr[nnodes] * NEQ[i] * NEQ[j];
+int64_t block_nnz(HostGraph const& g, int nnodes, int i, int j, int ndims) {
+  int const neq[2] = {ndims, 1};
+  return (int64_t)g.nodeptr[nnodes] * neq[i] * neq[j];
 }
 
-void block_csr(HostGraph const& g, int nnodes, int i, int j, int64_t* rowptr, int32_t* colidx) {
-  int const ni = NEQ[i], nj = NEQ[j];
+void block_csr(HostGraph const& g, int nnodes, int i, int j, int64_t* rowptr, int32_t* colidx, int ndims) {
+  int const neq[2] = {ndims, 1};
+  int const ni = neq[i], nj = neq[j];
   int64_t w = 0;
   rowptr[0] = 0;
   for (int n = 0; n < nnodes; ++n)

@@ -48,11 +48,11 @@ struct StagePlan {
 };
 void plan_staged_assembly(HostMesh const& m, HostGraph const& g, int min_chunk, int align, StagePlan& plan);
 
-// CSR of block (i,j), i,j in {0:u (3 eqs), 1:p (1 eq)}: row dof = node*neq_i+eq_i,
+// CSR of block (i,j), i,j in {0:u (ndims eqs: 3, or 2 on tri3 meshes), 1:p (1 eq)}: row dof = node*neq_i+eq_i,
 // columns sorted, all equations of a neighbour node contiguous -- the layout
 // Tpetra builds in compute_ghost_graph.
-int64_t block_nnz(HostGraph const& g, int nnodes, int i, int j);
-void block_csr(HostGraph const& g, int nnodes, int i, int j, int64_t* rowptr, int32_t* colidx);
+int64_t block_nnz(HostGraph const& g, int nnodes, int i, int j, int ndims = 3);
+void block_csr(HostGraph const& g, int nnodes, int i, int j, int64_t* rowptr, int32_t* colidx, int ndims = 3);
 
 // Greedy element colouring: elements of one colour share no node, so a launch
 // over one colour can read-modify-write CSR values and residual entries without

@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(BLOCK) k_forward_jacobian(MeshTables mt, Model
   int const lb = xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
   int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;
+  if (gib >= GPB) return;  // lanes left over when NDOF does not divide the block (tri3: 7 groups of 9)
   int const gi = lb * GPB + gib;
   if (gi >= count) return;
   int const e = mt.order ? mt.order[first + gi] : first + gi;
@@ -313,6 +314,7 @@ template <class E> static hipError_t launch_gather_rows(GatherArgs const& ga, in
   int const lb = xcd_block(blockIdx.x, nblocks);                              \
   if (lb >= nblocks) return;                                                  \
   int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;           \
+  if (gib >= GPB) return; /* lanes left over when NDOF does not divide the block (tri3: 7 groups of 9) */ \
   int const gi = lb * GPB + gib;                                              \
   if (gi >= count) return;                                                    \
   int const e = mt.order ? mt.order[first + gi] : first + gi;
@@ -357,6 +359,7 @@ __global__ void __launch_bounds__(BLOCK) k_param_gradient(MeshTables mt, ModelSe
   using Lane = GradLane<E, ModelT>;
   __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
   int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;
+  if (gib >= GPB) return;
   Lane L;
   L.slot = -1;
   L.acc = 0.;
@@ -372,6 +375,7 @@ __global__ void __launch_bounds__(BLOCK) k_qoi(MeshTables mt, FieldArgs fa, Adjo
   using Lane = QoiLane<E, ModelT>;
   __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
   int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;
+  if (gib >= GPB) return;
   Lane L;
   L.acc = 0.;
   GpuExec<Lane> ex(k, L);
@@ -487,6 +491,7 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.gather_rows = &launch_gather_rows<E>;
   ks.stage_stride = stage_stride<E>();
   ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements
+  ks.can_stage = E::DIM == 3;              // the stage and the row-sum kernel are laid out for 3 + 1 equations per node
   return ks;
 }
 
@@ -503,7 +508,18 @@ template <class E> static KernelSet kernel_set_for(int model) {
   return KernelSet{};
 }
 
+// 2-D meshes: the models the reference's 2-D decks run on `mechanics` with 2 + 1 equations per node
+static KernelSet kernel_set_2d(int model) {
+  switch (model) {
+    case MODEL_SMALL_J2: return kernel_set<Elem<C8_TRI3>, SmallJ2Plane>();
+    case MODEL_SMALL_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, SmallHillPlaneStrain>();
+  }
+  return KernelSet{};
+}
+
 KernelSet get_kernels(int elem_type, int model) {
+  if (elem_type == C8_TRI3) return kernel_set_2d(model);
+  if (model == MODEL_SMALL_HILL_PLANE_STRAIN) return KernelSet{};
   if (elem_type == C8_HEX8) return kernel_set_for<Elem<C8_HEX8>>(model);
   if (elem_type == C8_TET4) return kernel_set_for<Elem<C8_TET4>>(model);
   return KernelSet{};

@@ -7,7 +7,8 @@
 
 namespace c8 {
 
-enum { MODEL_NONE = -1, MODEL_ELASTIC = 0, MODEL_SMALL_J2 = 1, MODEL_HYPER_J2 = 2, MODEL_SMALL_HILL = 3, MODEL_ISOTROPIC_ELASTIC = 4, MODEL_HYPO_HILL = 5 };
+enum { MODEL_NONE = -1, MODEL_ELASTIC = 0, MODEL_SMALL_J2 = 1, MODEL_HYPER_J2 = 2, MODEL_SMALL_HILL = 3, MODEL_ISOTROPIC_ELASTIC = 4, MODEL_HYPO_HILL = 5,
+       MODEL_SMALL_HILL_PLANE_STRAIN = 6 };
 
 struct LaunchArgs {
   MeshTables mt;
@@ -40,6 +41,7 @@ struct KernelSet {
   GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage
   int stage_stride;            // doubles per element in the stage
   bool adjoint_slot_stages;    // the slot-per-lane K3 can store into the stage (it transposes through LDS first)
+  bool can_stage;              // staged (gather) assembly available for this element type
 };
 
 // registry keyed like the reference's string factories

@@ -282,5 +282,27 @@ template <class T> C8_HD Tens3<T> sym6(T const* s) {
 template <class T> C8_HD void pack_sym6(Tens3<T> const& t, T* s) {  // local_residual.cpp:572-577
   s[0] = t.xx; s[1] = t.xy; s[2] = t.xz; s[3] = t.yy; s[4] = t.yz; s[5] = t.zz;
 }
+// The same in DIM dimensions.  The reference's tensors have a run-time dimension (MiniTensor): on a 2-D mesh every
+// model works on 2 x 2 tensors and packs symmetric ones as (00,01,11) (local_residual.cpp:197-204, :565-570).  Here a
+// 2 x 2 tensor is a Tens3 whose out-of-plane entries are zero -- sums over nine entries then equal the sums over four.
+template <int DIM, class T> C8_HD Tens3<T> sym_dim(T const* s) {
+  if (DIM == 3) return sym6(s);
+  Tens3<T> r;
+  r.xx = s[0]; r.xy = s[1]; r.xz = T(0.);
+  r.yx = s[1]; r.yy = s[2]; r.yz = T(0.);
+  r.zx = T(0.); r.zy = T(0.); r.zz = T(0.);
+  return r;
+}
+template <int DIM, class T> C8_HD void pack_sym_dim(Tens3<T> const& t, T* s) {
+  if (DIM == 3) { pack_sym6(t, s); return; }
+  s[0] = t.xx; s[1] = t.xy; s[2] = t.yy;
+}
+// A - s I with I the DIM x DIM identity
+template <int DIM, class T, class S> C8_HD Tens3<T> minus_s_eye(Tens3<T> const& A, S const& s) {
+  Tens3<T> r = A;
+  r.xx = A.xx - s; r.yy = A.yy - s;
+  if (DIM == 3) r.zz = A.zz - s;
+  return r;
+}
 
 }  // namespace c8

@@ -141,8 +141,11 @@ template <class T> struct IsotropicElastic {
 };
 
 // ---- small_J2.cpp -------------------------------------------------------------
-template <class T> struct SmallJ2 {
-  static constexpr int NLOC = 7, NPARAMS = 6;
+// The reference's class serves 3-D and 2-D meshes (ndims = m_num_dims, eye<T>(ndims), small_J2.cpp:186-187): in 2-D it
+// works on 2 x 2 tensors -- the in-plane deviatoric stress without its out-of-plane entry -- with 3 + 1 local unknowns.
+template <class T, int DIM> struct SmallJ2Dim {
+  static constexpr int NSYM = (DIM == 3) ? 6 : 3;
+  static constexpr int NLOC = NSYM + 1, NPARAMS = 6;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
   static constexpr int WAVE_BLOCKS_PER_CU_K4 = 3;  // 162 registers: three waves per SIMD (3.1 against 3.5 ms per million elements)
@@ -152,7 +155,7 @@ template <class T> struct SmallJ2 {
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
   C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
   T params[NPARAMS];  // E nu K Y cte delta_T  (small_J2.cpp:70-75)
-  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain (00,01,02,11,12,22) or (00,01,11), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
   C8_HD void initial_guess(PointState<T> const&) {  // :127-135
     C8_UNROLL
@@ -161,13 +164,12 @@ template <class T> struct SmallJ2 {
   C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :266-277
     T const mu = compute_mu(params[0], params[1]);
     Tens3<T> const eps = small_strain(g.grad_u);
-    Tens3<T> const pstrain = sym6(xi);
-    return scale(2. * mu, dev(eps) - pstrain);
+    Tens3<T> const pstrain = sym_dim<DIM>(xi);
+    Tens3<T> const dev_eps = (DIM == 3) ? dev(eps) : minus_s_eye<DIM>(eps, trace(eps) * (1. / 3.));  // eps - tr(eps)/3 I(ndims)
+    return scale(2. * mu, dev_eps - pstrain);
   }
   C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :253-263
-    Tens3<T> s = dev_cauchy(g);
-    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
-    return s;
+    return minus_s_eye<DIM>(dev_cauchy(g), g.p);
   }
   C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :280-289
     T const E = params[0], nu = params[1];
@@ -180,7 +182,7 @@ template <class T> struct SmallJ2 {
     double const sqrt_32 = 1.22474487139158904910;
     T const mu = compute_mu(params[0], params[1]);
     T const K = params[2], Y = params[3];
-    T const alpha = xi[6], alpha_old = xi_prev[6];
+    T const alpha = xi[NSYM], alpha_old = xi_prev[NSYM];
     Tens3<T> const s = dev_cauchy(g);
     T const s_mag = norm(s);
     T const sigma_yield = Y + K * alpha;
@@ -191,9 +193,75 @@ template <class T> struct SmallJ2 {
     if (path == C8_PLASTIC_PATH) {
       T const dgam = sqrt_32 * (alpha - alpha_old);
       T const c = dgam / s_mag;  // dgam * n = (dgam/|s|) s
-      Tens3<T> const Rp = sym6(xi) - sym6(xi_prev) - scale(c, s);
-      pack_sym6(Rp, R);
-      R[6] = f;
+      Tens3<T> const Rp = sym_dim<DIM>(xi) - sym_dim<DIM>(xi_prev) - scale(c, s);
+      pack_sym_dim<DIM>(Rp, R);
+      R[NSYM] = f;
+    } else {
+      C8_UNROLL
+      for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
+    }
+    return path;
+  }
+};
+template <class T> struct SmallJ2 : SmallJ2Dim<T, 3> {};       // "small_J2" on a 3-D mesh
+template <class T> struct SmallJ2Plane : SmallJ2Dim<T, 2> {};  // "small_J2" on a 2-D mesh (notch2D_small_J2.yaml.in)
+
+// ---- small_hill_plane_strain.cpp (2-D meshes): Hill's yield function on the in-plane deviatoric stress completed by
+//      s_zz = 2 mu (-tr(eps)/3 + tr(pstrain)) (:226-233), Voce hardening, flow along the in-plane part of the Hill normal
+//      (:243-247); R02 = R12 = 1 -----------------------------------------------------------------------------------
+template <class T> struct SmallHillPlaneStrain {
+  static constexpr int NLOC = 4, NPARAMS = 9;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
+  T params[NPARAMS];  // E nu Y S D R00 R11 R22 R01  (small_hill_plane_strain.cpp:76-84)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain (00,01,11), alpha
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD void initial_guess(PointState<T> const&) {  // :140-148
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(xi_prev[k]));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :293-304
+    T const mu = compute_mu(params[0], params[1]);
+    Tens3<T> const eps = small_strain(g.grad_u);
+    return scale(2. * mu, minus_s_eye<2>(eps, trace(eps) * (1. / 3.)) - sym_dim<2>(xi));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const { return minus_s_eye<2>(dev_cauchy(g), g.p); }  // :280-290
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :307-315
+    return compute_kappa(params[0], params[1]) * trace(small_strain(g.grad_u));
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :193-277
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[3], D = params[4];
+    auto inv2 = [](T const& r) { return 1. / (r * r); };
+    T const i00 = inv2(params[5]), i11 = inv2(params[6]), i22 = inv2(params[7]);
+    T const F = 0.5 * (i11 + i22 - i00), G = 0.5 * (i22 + i00 - i11), H = 0.5 * (i00 + i11 - i22);  // compute_hill_params
+    T const N = 1.5 * inv2(params[8]);  // L, M belong to the out-of-plane shears, which vanish
+    T const alpha = xi[3], alpha_old = xi_prev[3];
+    Tens3<T> const ps = sym_dim<2>(xi);
+    Tens3<T> const s = dev_cauchy(g);
+    T const s_zz = (2. * mu) * (-(trace(small_strain(g.grad_u)) * (1. / 3.)) + trace(ps));
+    T const d12 = s.yy - s_zz, d20 = s_zz - s.xx, d01 = s.xx - s.yy;
+    T const hill = c8_sqrt(F * d12 * d12 + G * d20 * d20 + H * d01 * d01 + 2. * (N * s.xy * s.xy));  // compute_hill_value
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      Tens3<T> n = scale(0., ps);  // in-plane part of compute_hill_normal
+      n.xx = ((G + H) * s.xx - H * s.yy - G * s_zz) / hill;
+      n.yy = ((F + H) * s.yy - H * s.xx - F * s_zz) / hill;
+      n.xy = n.yx = N * s.xy / hill;
+      T const dgam = alpha - alpha_old;
+      pack_sym_dim<2>(ps - sym_dim<2>(xi_prev) - scale(dgam, n), R);
+      R[3] = f;
     } else {
       C8_UNROLL
       for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
@@ -554,11 +622,12 @@ struct QoiArgs {
   double c_avg, c_load;
   int comp;
   double const* S;  // [nelems][coupled points][3], null when c_load == 0
+  double ndims = 3.;  // "average displacement" divides by the number of dimensions (avg_disp.cpp:27)
 };
 struct PointQoi {
   template <class T, class Local>
   C8_HD static T evaluate(PointState<T> const& g, Local const& local, double wdv, QoiArgs const& qa, size_t qp) {
-    T v = (g.u[0] + g.u[1] + g.u[2]) * (qa.c_avg * wdv / 3.);
+    T v = (g.u[0] + g.u[1] + g.u[2]) * (qa.c_avg * wdv / qa.ndims);
     if (qa.c_load != 0.) {  // uniform over the launch
       Tens3<T> const Gu = Mechanics::flux_u(local, g);
       double const s0 = qa.S[qp * 3] * (qa.c_load * wdv), s1 = qa.S[qp * 3 + 1] * (qa.c_load * wdv),

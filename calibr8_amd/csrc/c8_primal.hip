@@ -17,22 +17,22 @@ using namespace c8;
 namespace {
 
 constexpr int TPB = 256;
-__host__ __device__ inline int neq_of(int i) { return i == 0 ? 3 : 1; }
+__host__ __device__ inline int neq_of(int i, int ndims) { return i == 0 ? ndims : 1; }
 
 // dbcs.cpp:68-118: one thread per constrained row
 __global__ void k_dirichlet(int n, int resid, int eq, int32_t const* nodes, double const* values, double const* x,
                             int32_t const* nodeptr, int32_t const* nodeadj, double* A_i0, double* A_i1, double* b,
-                            int is_adjoint, int nowned) {
+                            int is_adjoint, int nowned, int ndims) {
   int const t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   int const node = nodes[t];
   if (node >= nowned) return;  // multi-part mesh: the owner applies the condition to its OWNED row (node sets hold owned nodes, dbcs.cpp:66)
-  int const ni = neq_of(resid);
+  int const ni = neq_of(resid, ndims);
   int const row = node * ni + eq;
   int64_t const np = nodeptr[node], deg = nodeptr[node + 1] - np;
   double diag = 0.;
   for (int j = 0; j < 2; ++j) {
-    int const nj = neq_of(j);
+    int const nj = neq_of(j, ndims);
     double* vals = (j == 0 ? A_i0 : A_i1) + np * ni * nj + (int64_t)eq * deg * nj;  // start of this CSR row
     for (int64_t k = 0; k < deg; ++k)
       for (int e = 0; e < nj; ++e) {
@@ -82,9 +82,9 @@ __global__ void k_traction(int n, int npf, int32_t const* faces, double const* t
 
 // y_i[row] (+)= sum_k A_ij[row][k] x_j[col k]; one thread per row
 __global__ void k_spmv(int nnodes, int i, int j, int32_t const* nodeptr, int32_t const* nodeadj, double const* vals,
-                       double const* x, double* y, int accumulate) {
+                       double const* x, double* y, int accumulate, int ndims) {
   int const row = blockIdx.x * blockDim.x + threadIdx.x;
-  int const ni = neq_of(i), nj = neq_of(j);
+  int const ni = neq_of(i, ndims), nj = neq_of(j, ndims);
   if (row >= nnodes * ni) return;
   int const node = row / ni, eq = row - node * ni;
   int64_t const np = nodeptr[node], deg = nodeptr[node + 1] - np;
@@ -144,11 +144,11 @@ int c8_apply_dirichlet(c8_ctx* c, int n, const c8_dbc* dbcs, const double* const
   if (!c || n < 0 || (n > 0 && !dbcs) || !x || !sys) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: null argument");
   for (int q = 0; q < n; ++q) {  // in deck order: later conditions overwrite earlier ones on shared rows
     c8_dbc const& d = dbcs[q];
-    if (d.resid < 0 || d.resid > 1 || d.eq < 0 || d.eq >= neq_of(d.resid)) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: bad residual/equation index");
+    if (d.resid < 0 || d.resid > 1 || d.eq < 0 || d.eq >= neq_of(d.resid, c->ndims)) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: bad residual/equation index");
     if (d.n <= 0) continue;
     hipLaunchKernelGGL(k_dirichlet, dim3(grid_of(d.n)), dim3(TPB), 0, c->stream, d.n, d.resid, d.eq, d.nodes, d.values,
                        x[d.resid], c->d_nodeptr, c->d_nodeadj, sys->A[d.resid][0], sys->A[d.resid][1], sys->b[d.resid], is_adjoint,
-                       c->halo ? c8_halo_num_owned(c->halo) : c->mesh.nnodes);
+                       c->halo ? c8_halo_num_owned(c->halo) : c->mesh.nnodes, c->ndims);
     C8P_HIP(hipGetLastError());
   }
   return C8_OK;
@@ -156,6 +156,7 @@ int c8_apply_dirichlet(c8_ctx* c, int n, const c8_dbc* dbcs, const double* const
 
 int c8_apply_traction(c8_ctx* c, int n, const c8_tbc* tbcs, const c8_system* sys) {
   if (!c || n < 0 || (n > 0 && !tbcs) || !sys) return c8_fail(C8_ERR_ARG, "c8_apply_traction: null argument");
+  if (n > 0 && c->ndims != 3) return c8_fail(C8_ERR_UNSUPPORTED, "c8_apply_traction: tractions are built for the faces of 3-D elements");
   for (int q = 0; q < n; ++q) {
     c8_tbc const& t = tbcs[q];
     if (t.resid != 0 || (t.nodes_per_face != 3 && t.nodes_per_face != 4)) return c8_fail(C8_ERR_ARG, "c8_apply_traction: tractions act on residual 0 over tri3/quad4 faces");
@@ -194,8 +195,8 @@ int c8_apply_A(c8_ctx* c, const c8_system* sys, const double* const x[2], double
   if (!c || !sys || !x || !y) return c8_fail(C8_ERR_ARG, "c8_apply_A: null argument");
   for (int i = 0; i < 2; ++i)
     for (int j = 0; j < 2; ++j) {
-      hipLaunchKernelGGL(k_spmv, dim3(grid_of((size_t)c->mesh.nnodes * neq_of(i))), dim3(TPB), 0, c->stream, c->mesh.nnodes, i, j,
-                         c->d_nodeptr, c->d_nodeadj, sys->A[i][j], x[j], y[i], j);
+      hipLaunchKernelGGL(k_spmv, dim3(grid_of((size_t)c->mesh.nnodes * neq_of(i, c->ndims))), dim3(TPB), 0, c->stream, c->mesh.nnodes, i, j,
+                         c->d_nodeptr, c->d_nodeadj, sys->A[i][j], x[j], y[i], j, c->ndims);
       C8P_HIP(hipGetLastError());
     }
   return C8_OK;
@@ -221,9 +222,9 @@ struct StepSystem {
     parts = ctx->halo != nullptr;
     int const no = parts ? c8_halo_num_owned(ctx->halo) : ctx->mesh.nnodes;
     for (int i = 0; i < 2; ++i) {
-      nloc[i] = (size_t)ctx->mesh.nnodes * neq_of(i);
-      nown[i] = (size_t)no * neq_of(i);
-      for (int j = 0; j < 2; ++j) nnz[i][j] = (size_t)ctx->graph.nodeptr[ctx->mesh.nnodes] * neq_of(i) * neq_of(j);
+      nloc[i] = (size_t)ctx->mesh.nnodes * neq_of(i, ctx->ndims);
+      nown[i] = (size_t)no * neq_of(i, ctx->ndims);
+      for (int j = 0; j < 2; ++j) nnz[i][j] = (size_t)ctx->graph.nodeptr[ctx->mesh.nnodes] * neq_of(i, ctx->ndims) * neq_of(j, ctx->ndims);
     }
   }
   int zero() const {  // la->zero_all (linear_alg.cpp:118-129)

@@ -54,7 +54,7 @@ __global__ void k_add_scalar(double* x, double v) { *x += v; }
 // ---- used by c8_api.hip -------------------------------------------------------------------------------------
 // the point integrand of the adjoint kernels (K3, K5): x, xi or parameter derivatives of the objective
 QoiArgs c8_qoi_args(c8_ctx const* c) {
-  if (c->qoi_kind == 0) return QoiArgs{1., 0., 0, nullptr};
+  if (c->qoi_kind == 0) return QoiArgs{1., 0., 0, nullptr, (double)c->ndims};
   return QoiArgs{0., c->cal_balance * c->cal_dt_over_T * c->cal_load_mismatch, c->cal_comp, c->d_cal_S};
 }
 
@@ -111,6 +111,7 @@ int c8_set_qoi_avg_disp(c8_ctx* c) {
 
 int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
   if (!c || !d || d->num_faces < 0 || (d->num_faces > 0 && !d->faces)) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: bad argument");
+  if (c->ndims != 3) return c8_fail(C8_ERR_UNSUPPORTED, "c8_set_qoi_calibration: the calibration objective is built in its 3-D form (calibration.cpp:32-34 is the 2-D branch)");
   int const nn = c->mesh.nn, nfn = (nn == 4) ? 3 : 4, nfe = (nn == 4) ? 4 : 6;
   if (d->num_faces > 0 && d->nodes_per_face != nfn) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: faces must have 3 nodes (tet4) or 4 (hex8)");
   if (d->coord_idx < 0 || d->coord_idx > 2 || d->reaction_comp < 0 || d->reaction_comp > 2) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: coordinate index / component out of range");

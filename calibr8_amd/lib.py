@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libc8.so")
 
-C8_ELEM_TET4, C8_ELEM_HEX8 = 4, 8
+C8_ELEM_TRI3, C8_ELEM_TET4, C8_ELEM_HEX8 = 3, 4, 8
 C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED, C8_NOT_CONVERGED = 0, -1, -2, -3, -4, -5
 C8_SCATTER_ATOMIC, C8_SCATTER_COLORED, C8_SCATTER_GATHER = 0, 1, 2
 C8_KERNEL_AUTO, C8_KERNEL_SLOT, C8_KERNEL_WAVE = 0, 1, 2
@@ -98,6 +98,7 @@ SYMBOLS = [
     ("c8_last_error", C.c_char_p, []),
     ("c8_build_info", C.c_char_p, []),
     ("c8_num_local_dofs", C.c_int, [C.c_void_p]),
+    ("c8_num_dims", C.c_int, [C.c_void_p]),
     ("c8_num_local_points", C.c_int, [C.c_void_p]),
     ("c8_num_colors", C.c_int, [C.c_void_p]),
     ("c8_graph_nnz", C.c_int64, [C.c_void_p, C.c_int, C.c_int]),

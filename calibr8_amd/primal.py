@@ -20,6 +20,7 @@ def scipy_solver(asm):
     n = asm.nnodes
     rp, ci = asm.rowptr, asm.colidx
     nnz = asm.nnz
+    NEQ = asm.neq
 
     def solve(user, sys_p, dx_p):
         sys = sys_p.contents
@@ -30,8 +31,8 @@ def scipy_solver(asm):
                 blocks[i][j] = sp.csr_matrix((vals, ci[i][j], rp[i][j]), shape=(n * NEQ[i], n * NEQ[j]))
         b = np.concatenate([_DevView(sys.b[i], n * NEQ[i], asm.device).to_numpy() for i in range(2)])
         x = spla.spsolve(sp.bmat(blocks, format="csc"), b)
-        _DevView(dx_p[0], n * 3, asm.device).from_numpy(x[: n * 3])
-        _DevView(dx_p[1], n, asm.device).from_numpy(x[n * 3:])
+        _DevView(dx_p[0], n * NEQ[0], asm.device).from_numpy(x[: n * NEQ[0]])
+        _DevView(dx_p[1], n, asm.device).from_numpy(x[n * NEQ[0]:])
         return 0
 
     return _l.LINEAR_SOLVE_FN(solve)
@@ -132,7 +133,7 @@ class PrimalDriver:
         self.opts = _l.NewtonOpts(max_iters, abs_tol, rel_tol, int(line_search), 1e-4, 0.5, 0.9, 4)
         self.solver = solver if solver is not None else scipy_solver(asm)
         dev = asm.device
-        self.u = [torch.zeros(asm.nnodes * 3, dtype=torch.float64, device=dev)]
+        self.u = [torch.zeros(asm.nnodes * asm.ndims, dtype=torch.float64, device=dev)]
         self.p = [torch.zeros(asm.nnodes, dtype=torch.float64, device=dev)]
         self.xi = [asm.new_state()]
         self.ls = asm.new_linsys()
@@ -219,7 +220,7 @@ def adjoint_gradient(primal, nparams):
     f = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=dev)
     phi = torch.zeros_like(g)
     grad = torch.zeros(nparams, dtype=torch.float64, device=dev)
-    z_u = torch.zeros(asm.nnodes * 3, dtype=torch.float64, device=dev)
+    z_u = torch.zeros(asm.nnodes * asm.ndims, dtype=torch.float64, device=dev)
     z_p = torch.zeros(asm.nnodes, dtype=torch.float64, device=dev)
     sy = primal.ls.c_struct()
     zero_vals = [asm.dev(np.zeros(len(nodes))) for _, _, nodes, _ in primal.dbcs]

@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct c8_ctx c8_ctx;
 
-enum { C8_ELEM_TET4 = 4, C8_ELEM_HEX8 = 8 };
+enum { C8_ELEM_TRI3 = 3, C8_ELEM_TET4 = 4, C8_ELEM_HEX8 = 8 };
 enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -3, C8_ERR_UNSUPPORTED = -4 };
 /* ATOMIC: one launch, f64 atomic adds.  COLORED: one launch per element colour, plain adds, reproducible.
  * GATHER: element matrices are staged element-major in a context-owned buffer (8.4 KB per hex8, 2.2 KB per
@@ -49,7 +49,9 @@ enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2 };
 /* One mesh part (what Disc holds after loadMdsMesh, disc.cpp:31-39): all nodes that touch a
  * local element, local (GHOST) numbering. */
 typedef struct {
-  int32_t elem_type;       /* C8_ELEM_TET4 (what the reference runs, disc.cpp:165) or C8_ELEM_HEX8 */
+  int32_t elem_type;       /* C8_ELEM_TET4 / C8_ELEM_TRI3 (what the reference runs in 3-D / 2-D, disc.cpp:165) or
+                              C8_ELEM_HEX8.  On a tri3 mesh `mechanics` has 2 + 1 equations per node (mechanics.cpp:34):
+                              every u array is [num_nodes*2]; coords stay [num_nodes][3] with z = 0. */
   int32_t num_nodes;
   int32_t num_elems;
   int32_t num_elem_sets;   /* material blocks, disc->num_elem_sets() */
@@ -68,14 +70,16 @@ typedef struct {
 typedef struct {
   const char* global_type;          /* "mechanics" (mixed u-p formulation) */
   const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" | "small_hill" | "isotropic_elastic" |
-                                       "hypo_hill"  (the names of local_residual.cpp:893-933) */
+                                       "hypo_hill"; on tri3 meshes "small_J2" | "small_hill_plane_strain"
+                                       (the names of local_residual.cpp:893-933) */
   double stabilization_multiplier;  /* mechanics.cpp:47 */
   int32_t local_max_iters;          /* "nonlinear max iters" of the local residual */
   double local_abs_tol;             /* "nonlinear absolute tol" */
   double local_rel_tol;             /* "nonlinear relative tol" */
   int32_t num_params;               /* elastic 4 (E nu cte delta_T), small_J2 6 (E nu K Y cte delta_T),
                                        hyper_J2 8 (E nu Y S D A n K), small_hill / hypo_hill 11 (E nu Y R00 R11 R22
-                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu) */
+                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu), small_hill_plane_strain 9
+                                       (E nu Y S D R00 R11 R22 R01) */
   const double* params;             /* [num_elem_sets][num_params] */
 } c8_model_desc;
 
@@ -105,7 +109,8 @@ const char* c8_last_error(void);
 const char* c8_build_info(void);
 
 /* ---- discretisation queries (host arrays) ------------------------------------------------ */
-int c8_num_local_dofs(const c8_ctx* ctx);    /* LocalResidual::num_dofs: 1 / 7 / 8 */
+int c8_num_local_dofs(const c8_ctx* ctx);    /* LocalResidual::num_dofs: 1 / 7 / 8 (3-D), 4 (2-D) */
+int c8_num_dims(const c8_ctx* ctx);          /* 3, or 2 on a tri3 mesh: equations per node of residual 0 */
 int c8_num_local_points(const c8_ctx* ctx);  /* points of the local-state field per element */
 int c8_num_colors(const c8_ctx* ctx);
 /* Block (i,j) CSR graph = m_graphs[GHOST][i][j] (disc.cpp:356-387): sorted columns. */

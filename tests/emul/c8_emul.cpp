@@ -211,6 +211,17 @@ template <template <class> class ModelT> static void run_qoi_wave(Call const& c)
   delete sh;
 }
 
+// 2-D meshes (tri3): the slot kernels with the 2-D models
+static int dispatch_2d(std::string const& model, Call const& c) {
+  using E = Elem<C8_TRI3>;
+  if (c.what != K_FORWARD && c.what != K_RESIDUAL && c.what != K_ADJ_JAC && c.what != K_ADJ_LOCAL && c.what != K_GRAD && c.what != K_QOI) return -4;
+  if (c.staged) return -4;
+  if (model == "small_J2") run<E, SmallJ2Plane>(c);
+  else if (model == "small_hill_plane_strain") run<E, SmallHillPlaneStrain>(c);
+  else return -2;
+  return 0;
+}
+
 template <class E> static int dispatch(std::string const& model, Call const& c) {
   if (c.what == K_QOI_WAVE) {
     if (E::TYPE != C8_HEX8) return -4;
@@ -307,8 +318,11 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
   c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
   c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};
-  c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active, QoiArgs{1., 0., 0, nullptr}};
-  auto run_it = [&]() { return (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c); };
+  c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active, QoiArgs{1., 0., 0, nullptr, elem_type == C8_TRI3 ? 2. : 3.}};
+  auto run_it = [&]() {
+    if (elem_type == C8_TRI3) return dispatch_2d(local_type, c);
+    return (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c);
+  };
   int const base = c.what;
   bool const is_qoi = base == K_QOI || base == K_QOI_WAVE, is_k3 = base == K_ADJ_JAC || base == K_ADJ_JAC_WAVE,
              is_k5 = base == K_GRAD || base == K_GRAD_WAVE, is_pre = base == K_QOI_PREPROCESS;

@@ -8,7 +8,7 @@ from calibr8_amd import Assembler
 class HostLinSys:
     def __init__(self, gb):
         self.A = [[np.zeros(gb.asm.nnz[i][j]) for j in range(2)] for i in range(2)]
-        self.b = [np.zeros(gb.nnodes * 3), np.zeros(gb.nnodes)]
+        self.b = [np.zeros(gb.nnodes * gb.ndims), np.zeros(gb.nnodes)]
 
     def zero(self):
         for i in range(2):
@@ -24,6 +24,7 @@ class GpuBackend:
             self.asm.set_kernel(kernel)
         a = self.asm
         self.nnodes, self.nelems, self.nn = a.nnodes, a.nelems, a.nn
+        self.ndims = a.ndims
         self.npts, self.nloc = a.npts, a.nloc
         self.rowptr, self.colidx = a.rowptr, a.colidx
         self._ls = a.new_linsys()

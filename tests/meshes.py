@@ -22,6 +22,38 @@ def brick(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
     return coords, conn, sets
 
 
+def tri_mesh(nx, ny, lx=1.0, ly=1.0):
+    """Structured tri3 mesh of a rectangle (each cell split along alternating diagonals), counter-clockwise triangles;
+    coords [n][3] with z = 0 (the layout the 2-D path takes)."""
+    xs, ys = np.linspace(0, lx, nx + 1), np.linspace(0, ly, ny + 1)
+    Y, X = np.meshgrid(ys, xs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+    nid = lambda i, j: j * (nx + 1) + i
+    tris = []
+    for j in range(ny):
+        for i in range(nx):
+            a, b, c, d = nid(i, j), nid(i + 1, j), nid(i + 1, j + 1), nid(i, j + 1)
+            tris += [[a, b, c], [a, c, d]] if (i + j) % 2 == 0 else [[a, b, d], [b, c, d]]
+    tol = 1e-12
+    sets = {"xmin": np.where(coords[:, 0] < tol)[0], "xmax": np.where(coords[:, 0] > lx - tol)[0],
+            "ymin": np.where(coords[:, 1] < tol)[0], "ymax": np.where(coords[:, 1] > ly - tol)[0]}
+    return coords, np.array(tris, dtype=np.int32), sets
+
+
+def jiggle_2d(coords, sets, amp, seed=7):
+    """jiggle() in the plane (z stays 0)"""
+    c = jiggle(coords, sets, amp, seed)
+    c[:, 2] = 0.0
+    return c
+
+
+def fields_for(ndims, u, p):
+    """a prescribed 3-D field pair restricted to the in-plane components for a 2-D mesh"""
+    if ndims == 3:
+        return u, p
+    return np.ascontiguousarray(u.reshape(-1, 3)[:, :2].ravel()), p
+
+
 def jiggle(coords, sets, amp, seed=7):
     """Perturb interior nodes so elements are not parallelepipeds (exercises the full Jacobian)."""
     rng = np.random.default_rng(seed)

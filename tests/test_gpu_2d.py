@@ -1,0 +1,102 @@
+"""`-m gpu`: the 2-D path on the device (tri3 elements, `mechanics` with 2 + 1 equations per node; SURVEY.md section 8
+f4): every entry point against the oracle at 1e-12, and the reference's two `mechanics` decks on the notch2D mesh end to
+end on the GPU (HIP assembly, device boundary conditions, the C++ Newton driver)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from parity_cases import CASES_2D, check_adjoint_chain, check_forward, check_residual, mesh_2d
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("scatter", ["colored", "atomic"])
+@pytest.mark.parametrize("mesh", ["structured", "notch2D"])
+@pytest.mark.parametrize("model,params,eps", CASES_2D)
+def test_2d_kernels_match_oracle(model, params, eps, mesh, scatter):
+    from gpu_backend import GpuBackend
+    et, c, conn = mesh_2d(mesh)
+    orc = ol.Oracle(et, c, conn, model, params)
+    gpu = GpuBackend(et, c, conn, model, params, scatter=scatter)
+    assert gpu.ndims == 2 and gpu.nloc == 4
+    check_forward(orc, gpu, c, model, eps, 1e-12)
+    check_residual(orc, gpu, c, eps, 1e-12)
+    check_adjoint_chain(orc, gpu, c, model, eps, 1e-12)
+
+
+def test_2d_default_mode_and_refusals():
+    from calibr8_amd import Assembler
+    from calibr8_amd.lib import C8Error
+    et, c, conn = mesh_2d("structured")
+    asm = Assembler(3, c, conn, "small_J2", [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0])
+    assert asm.scatter == "colored" and asm.ndims == 2 and asm.ndofs == 9  # no staged assembly for 2 + 1 equations per node
+    with pytest.raises(C8Error):
+        asm.set_scatter("gather")
+    with pytest.raises(C8Error):  # 3-D-only models are refused on a 2-D mesh
+        Assembler(3, c, conn, "hyper_J2", [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0])
+    with pytest.raises(C8Error):  # and the plane-strain model on a 3-D mesh
+        from meshes import brick
+        c3, conn3, _ = brick(2, 2, 2)
+        Assembler(8, c3, conn3, "small_hill_plane_strain", [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0])
+
+
+def notch2d():
+    d = json.load(open(os.path.join(HERE, "golden", "notch2D_tri3.json")))
+    return np.array(d["coords"]), np.array(d["conn"], dtype=np.int32), {k: np.array(v, dtype=np.int32) for k, v in d["node_sets"].items()}
+
+
+@pytest.mark.parametrize("deck", ["notch2D_small_J2", "notch2D_small_J2_plane_strain"])
+def test_notch2D_regressions_with_device_newton_driver(deck):
+    # test/primal/notch2D_small_J2.yaml.in (8 steps, Y 10) and notch2D_small_J2_plane_strain.yaml.in
+    # (`small_hill_plane_strain`, 4 steps): assembly, Dirichlet rows, norms, updates and line search on the device
+    from calibr8_amd import Assembler
+    from calibr8_amd.primal import PrimalDriver
+    c, conn, ns = notch2d()
+    if deck == "notch2D_small_J2":
+        model, params, nsteps, iters, pin, tol = "small_J2", [1000.0, 0.25, 100.0, 10.0, 0.0, 0.0], 8, 15, 6.55208497250819866e-03, 2e-5
+    else:
+        model, params, nsteps, iters, pin, tol = "small_hill_plane_strain", [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0], 4, 30, 1.7664579853744898e-03, 1e-10
+    asm = Assembler(3, c, conn, model, params)
+    dbcs = [(0, 0, ns["xmin"], lambda x, y, z, t: 0.0), (0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            (0, 1, ns["ymax"], lambda x, y, z, t: 0.001 * t)]
+    drv = PrimalDriver(asm, dbcs, max_iters=iters, abs_tol=1e-8, rel_tol=1e-8).solve(nsteps)
+    J = drv.qoi()
+    assert abs(J - pin) / pin < tol, (deck, J, pin)
+    # the oracle-driven host driver takes the same Newton iterations and lands on the same objective
+    from fe_driver import Dbc, Primal
+    orc = ol.Oracle(ol.TRI3, c, conn, model, params)
+    pr = Primal(orc, c, [Dbc(r, e, n, f) for r, e, n, f in dbcs], max_iters=iters, abs_tol=1e-8, rel_tol=1e-8).solve(nsteps)
+    assert drv.newton_iters == pr.newton_iters, (drv.newton_iters, pr.newton_iters)
+    assert abs(J - pr.qoi()) < 1e-10 * abs(J)
+    assert float(drv.xi[-1][:, :, 3].max()) > 1e-3
+
+
+def test_notch2D_adjoint_gradient_on_device_passes_fd_check():
+    # adjoint/notch2D_small_J2_adjoint_check.yaml.in with every step on the device: the adjoint gradient against
+    # central differences of the device objective along the deck's direction (all four parameters)
+    from calibr8_amd import Assembler
+    from calibr8_amd.primal import PrimalDriver, adjoint_gradient
+    c, conn, ns = notch2d()
+    dbcs = [(0, 0, ns["xmin"], lambda x, y, z, t: 0.0), (0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            (0, 1, ns["ymax"], lambda x, y, z, t: 0.001 * t)]
+    p0 = np.array([1000.0, 0.25, 100.0, 2.0, 0.0, 0.0])
+    span = np.array([100.0, 0.05, 10.0, 1.0])
+
+    def solve(p):
+        asm = Assembler(3, c, conn, "small_J2", list(p))
+        asm.set_active(0, [0, 1, 2, 3])
+        return PrimalDriver(asm, dbcs, max_iters=15, abs_tol=1e-12, rel_tol=1e-12).solve(4)
+
+    drv = solve(p0)
+    gd = float(adjoint_gradient(drv, 4) * span @ np.full(4, 0.1))
+    errs = []
+    for h in (1e-2, 1e-3, 1e-4):
+        pp, pm = p0.copy(), p0.copy()
+        pp[:4] += h * 0.1 * span
+        pm[:4] -= h * 0.1 * span
+        errs.append(abs((solve(pp).qoi() - solve(pm).qoi()) / (2 * h) - gd))
+    assert min(errs) < 1e-6 * abs(gd), (errs, gd)
