@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-1 closing profile batch (runs on the GPU box from the repo root)
+# closing profile batch of a round (runs on the GPU box from the repo root)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-batch}
