@@ -42,6 +42,8 @@ static int model_id(char const* name, int ndims, int* nloc, int* nparams) {
   if (ndims == 2) {  // the models of the reference's 2-D decks that run on `mechanics` (2 + 1 equations per node)
     if (s == "small_J2") { *nloc = SmallJ2Plane<double>::NLOC; *nparams = SmallJ2Plane<double>::NPARAMS; return MODEL_SMALL_J2; }
     if (s == "small_hill_plane_strain") { *nloc = SmallHillPlaneStrain<double>::NLOC; *nparams = SmallHillPlaneStrain<double>::NPARAMS; return MODEL_SMALL_HILL_PLANE_STRAIN; }
+    if (s == "hypo_hill_plane_strain") { *nloc = HypoHillPlaneStrain<double>::NLOC; *nparams = HypoHillPlaneStrain<double>::NPARAMS; return MODEL_HYPO_HILL_PLANE_STRAIN; }
+    if (s == "hyper_J2_plane_strain") { *nloc = HyperJ2PlaneStrain<double>::NLOC; *nparams = HyperJ2PlaneStrain<double>::NPARAMS; return MODEL_HYPER_J2_PLANE_STRAIN; }
     return MODEL_NONE;
   }
   if (s == "elastic") { *nloc = Elastic<double>::NLOC; *nparams = Elastic<double>::NPARAMS; return MODEL_ELASTIC; }
@@ -212,6 +214,8 @@ int c8_init_variables(const c8_ctx* c, double* xi) {
       case MODEL_ELASTIC: Elastic<double>::init_variables(x); break;
       case MODEL_SMALL_J2: if (c->ndims == 2) SmallJ2Plane<double>::init_variables(x); else SmallJ2<double>::init_variables(x); break;
       case MODEL_SMALL_HILL_PLANE_STRAIN: SmallHillPlaneStrain<double>::init_variables(x); break;
+      case MODEL_HYPER_J2_PLANE_STRAIN: HyperJ2PlaneStrain<double>::init_variables(x); break;
+      case MODEL_HYPO_HILL_PLANE_STRAIN: HypoHillPlaneStrain<double>::init_variables(x); break;
       case MODEL_HYPER_J2: HyperJ2<double>::init_variables(x); break;
       case MODEL_SMALL_HILL: SmallHill<double>::init_variables(x); break;
       case MODEL_ISOTROPIC_ELASTIC: IsotropicElastic<double>::init_variables(x); break;

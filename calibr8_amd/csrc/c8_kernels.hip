@@ -513,13 +513,15 @@ static KernelSet kernel_set_2d(int model) {
   switch (model) {
     case MODEL_SMALL_J2: return kernel_set<Elem<C8_TRI3>, SmallJ2Plane>();
     case MODEL_SMALL_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, SmallHillPlaneStrain>();
+    case MODEL_HYPER_J2_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, HyperJ2PlaneStrain>();
+    case MODEL_HYPO_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, HypoHillPlaneStrain>();
   }
   return KernelSet{};
 }
 
 KernelSet get_kernels(int elem_type, int model) {
   if (elem_type == C8_TRI3) return kernel_set_2d(model);
-  if (model == MODEL_SMALL_HILL_PLANE_STRAIN) return KernelSet{};
+  if (model == MODEL_SMALL_HILL_PLANE_STRAIN || model == MODEL_HYPER_J2_PLANE_STRAIN || model == MODEL_HYPO_HILL_PLANE_STRAIN) return KernelSet{};
   if (elem_type == C8_HEX8) return kernel_set_for<Elem<C8_HEX8>>(model);
   if (elem_type == C8_TET4) return kernel_set_for<Elem<C8_TET4>>(model);
   return KernelSet{};

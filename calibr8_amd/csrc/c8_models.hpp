@@ -270,6 +270,100 @@ template <class T> struct SmallHillPlaneStrain {
   }
 };
 
+// ---- hyper_J2_plane_strain.cpp (2-D meshes): finite-deformation J2 in plane strain.  Local unknowns zeta (00,01,11), Ie,
+//      alpha; the in-plane tensors are completed out of plane where the 3-D quantity is needed: zeta_zz = -tr(zeta),
+//      be_bar_zz = (zeta_zz + Ie) / det(rF)^(2/3).  The deformation gradient is F = grad u + I with the out-of-plane
+//      stretch 1, so the 3 x 3 determinant, inverse and cofactor are the 2 x 2 ones. ------------------------------------
+template <class T> struct HyperJ2PlaneStrain {
+  static constexpr int NLOC = 5, NPARAMS = 6;
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  T params[NPARAMS];  // E nu K Y Y_inf delta  (hyper_J2_plane_strain.cpp:76-81)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];
+  C8_HD static void init_variables(double* xi0) {  // :119-131
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) xi0[k] = 0.;
+    xi0[3] = 1.;
+  }
+  // the trial state depends on F, F_prev and the previous local state only (eval_be_bar_plane_strain :134-156)
+  struct Trial { T zeta_trial[3], Ie_trial; };
+  C8_HD Trial trial(PointState<T> const& g) const {
+    Tens3<T> const I = eye3<T>();
+    Tens3<T> const rF = matmul(g.grad_u + I, inverse(g.grad_u_prev + I));
+    T const det_rF_13 = c8_cbrt(det(rF));
+    Tens3<T> const rF_bar = scale(1. / det_rF_13, rF);
+    Tens3<T> inner = sym_dim<2>(xi_prev);  // zeta_old + Ie_old I(2)
+    inner.xx = inner.xx + xi_prev[3];
+    inner.yy = inner.yy + xi_prev[3];
+    Tens3<T> const be2 = matmul(matmul(rF_bar, inner), transpose(rF_bar));
+    T const zeta_zz = -(xi_prev[0] + xi_prev[2]);
+    T const be_zz = (zeta_zz + xi_prev[3]) / (det_rF_13 * det_rF_13);
+    Trial t;
+    t.Ie_trial = (be2.xx + be2.yy + be_zz) / 3.;
+    t.zeta_trial[0] = be2.xx - t.Ie_trial;
+    t.zeta_trial[1] = be2.xy;
+    t.zeta_trial[2] = be2.yy - t.Ie_trial;
+    return t;
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // :168-184
+    Trial const t = trial(g);
+    C8_UNROLL
+    for (int k = 0; k < 3; ++k) set_val(xi[k], val(t.zeta_trial[k]));
+    set_val(xi[3], val(t.Ie_trial));
+    set_val(xi[4], val(xi_prev[4]));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :340-351
+    T const mu = compute_mu(params[0], params[1]);
+    T const J = det(g.grad_u + eye3<T>());
+    return scale(mu / J, sym_dim<2>(xi));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const { return minus_s_eye<2>(dev_cauchy(g), g.p); }  // :328-337
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :354-365
+    T const kappa = compute_kappa(params[0], params[1]);
+    T const J = det(g.grad_u + eye3<T>());
+    return (kappa * 0.5) * (J - 1. / J);
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {
+    return evaluate(g, abs_tol, trial(g), force_path, path_in);
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const& tr, bool force_path = false, int path_in = 0) {  // :231-325
+    double const sqrt_23 = 0.81649658092772603273;
+    double const sqrt_32 = 1.22474487139158904910;
+    T const mu = compute_mu(params[0], params[1]);
+    T const K = params[2], Y = params[3], Y_inf = params[4], delta = params[5];
+    T const Ie = xi[3], alpha = xi[4], alpha_old = xi_prev[4];
+    Tens3<T> const zeta = sym_dim<2>(xi);
+    T const zeta_zz = -(xi[0] + xi[2]);
+    Tens3<T> s3 = scale(mu, zeta);  // s_3D = mu zeta_3D
+    s3.zz = mu * zeta_zz;
+    T const s_mag = norm(s3);
+    T const sigma_yield = Y + K * alpha + (Y_inf - Y) * (1. - c8_exp(-(delta * alpha)));
+    T const f = (s_mag - sqrt_23 * sigma_yield) / val(mu);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    Tens3<T> Rz = zeta - sym_dim<2>(tr.zeta_trial);
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = sqrt_32 * (alpha - alpha_old);
+      T const c = (2. * dgam) * Ie * mu / s_mag;  // 2 dgam Ie n_2D, n_2D = mu zeta / |s_3D|
+      Rz = Rz + scale(c, zeta);
+      Tens3<T> be = zeta;  // be_bar_3D = zeta_3D + Ie I(3)
+      be.xx = be.xx + Ie; be.yy = be.yy + Ie; be.zz = zeta_zz + Ie;
+      R[3] = det(be) - 1.;
+      R[4] = f;
+    } else {
+      R[3] = Ie - tr.Ie_trial;
+      R[4] = alpha - alpha_old;
+    }
+    pack_sym_dim<2>(Rz, R);
+    return path;
+  }
+};
+
 // ---- small_hill.cpp (Hill's anisotropic yield function, yield_functions.hpp:34-99; Voce hardening) ---------
 template <class T> struct SmallHill {
   static constexpr int NLOC = 7, NPARAMS = 11;
@@ -437,6 +531,103 @@ template <class T> struct HypoHill {
       R[6] = alpha - alpha_old;
     }
     pack_sym6(Rt, R);
+    return path;
+  }
+};
+
+// ---- hypo_hill_plane_strain.cpp (2-D meshes): the rate form of hypo_hill on in-plane kinematics, the out-of-plane
+//      stress as an extra unknown.  Local unknowns TC (00,01,11), alpha, TC_zz; residuals are NOT scaled by 1/mu here.  The
+//      polar rotation of F = grad u + I with unit out-of-plane stretch is the in-plane rotation completed by 1. ----------
+template <class T> struct HypoHillPlaneStrain {
+  static constexpr int NLOC = 5, NPARAMS = 9;
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  T params[NPARAMS];  // E nu Y S D R00 R11 R22 R01  (hypo_hill_plane_strain.cpp:84-92)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }  // :124-140
+  // d = R^T sym((F - F_prev) F^-1) R depends on F and F_prev only (eval_d :143-156)
+  struct Trial { T d[3]; };
+  C8_HD Trial trial(PointState<T> const& g) const {
+    Tens3<T> const I = eye3<T>();
+    Tens3<T> const F = g.grad_u + I;
+    Tens3<T> const F_prev = g.grad_u_prev + I;
+    Tens3<T> const Rot = polar_rotation(F);
+    Tens3<T> const L = matmul(F - F_prev, inverse(F));
+    Tens3<T> const D = scale(0.5, L + transpose(L));
+    Trial t;
+    pack_sym_dim<2>(matmul(matmul(transpose(Rot), D), Rot), t.d);
+    return t;
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // :168-186: elastic predictor, values only
+    double const E = val(params[0]), nu = val(params[1]);
+    double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+    Trial const t = trial(g);
+    double const ltr = lambda * (val(t.d[0]) + val(t.d[2]));
+    set_val(xi[0], val(xi_prev[0]) + ltr + 2. * mu * val(t.d[0]));
+    set_val(xi[1], val(xi_prev[1]) + 2. * mu * val(t.d[1]));
+    set_val(xi[2], val(xi_prev[2]) + ltr + 2. * mu * val(t.d[2]));
+    set_val(xi[3], val(xi_prev[3]));
+    set_val(xi[4], val(xi_prev[4]) + ltr);
+  }
+  C8_HD Tens3<T> rotated_cauchy(PointState<T> const& g) const {  // :332-341
+    Tens3<T> const Rot = polar_rotation(g.grad_u + eye3<T>());
+    return matmul(matmul(Rot, sym_dim<2>(xi)), transpose(Rot));
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const { return (trace(rotated_cauchy(g)) + xi[4]) / 3.; }  // :365-369
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :355-362
+    Tens3<T> const RC = rotated_cauchy(g);
+    return minus_s_eye<2>(RC, (trace(RC) + xi[4]) / 3.);
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const { return minus_s_eye<2>(dev_cauchy(g), g.p); }  // :343-352
+  // both at once (one polar decomposition instead of two); Mechanics::flux_coupled uses it
+  C8_HD void cauchy_and_hydro(PointState<T> const& g, Tens3<T>& sigma, T& sigma_h) const {
+    Tens3<T> const RC = rotated_cauchy(g);
+    sigma_h = (trace(RC) + xi[4]) / 3.;
+    sigma = minus_s_eye<2>(minus_s_eye<2>(RC, sigma_h), g.p);
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {
+    return evaluate(g, abs_tol, trial(g), force_path, path_in);
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const& tr, bool force_path = false, int path_in = 0) {  // :232-329
+    T const lambda = compute_lambda(params[0], params[1]);
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[3], D = params[4];
+    auto inv2 = [](T const& r) { return 1. / (r * r); };
+    T const i00 = inv2(params[5]), i11 = inv2(params[6]), i22 = inv2(params[7]);
+    T const F = 0.5 * (i11 + i22 - i00), G = 0.5 * (i22 + i00 - i11), H = 0.5 * (i00 + i11 - i22);  // compute_hill_params
+    T const N = 1.5 * inv2(params[8]);
+    T const alpha = xi[3], alpha_old = xi_prev[3], TC_zz = xi[4];
+    Tens3<T> const TC = sym_dim<2>(xi);
+    T const d12 = TC.yy - TC_zz, d20 = TC_zz - TC.xx, d01 = TC.xx - TC.yy;
+    T const phi = c8_sqrt(F * d12 * d12 + G * d20 * d20 + H * d01 * d01 + 2. * (N * TC.xy * TC.xy));  // compute_hill_value
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (phi - sigma_yield) / val(mu);
+    Tens3<T> const d = sym_dim<2>(tr.d);
+    T const ltr = lambda * trace(d);
+    Tens3<T> Rt = minus_s_eye<2>(TC - sym_dim<2>(xi_prev), ltr) - scale(2. * mu, d);
+    T Rzz = TC_zz - xi_prev[4] - ltr;
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      Tens3<T> n = scale(0., TC);  // in-plane part of compute_hill_normal
+      n.xx = ((G + H) * TC.xx - H * TC.yy - G * TC_zz) / phi;
+      n.yy = ((F + H) * TC.yy - H * TC.xx - F * TC_zz) / phi;
+      n.xy = n.yx = N * TC.xy / phi;
+      T const dgam = alpha - alpha_old;
+      Tens3<T> const dp = scale(dgam, n);
+      Rt = Rt + scale(2. * mu, dp);
+      Rzz = Rzz + (2. * mu) * (-(dp.xx + dp.yy));
+      R[3] = f;
+    } else {
+      R[3] = alpha - alpha_old;
+    }
+    pack_sym_dim<2>(Rt, R);
+    R[4] = Rzz;
     return path;
   }
 };

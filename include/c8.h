@@ -70,7 +70,8 @@ typedef struct {
 typedef struct {
   const char* global_type;          /* "mechanics" (mixed u-p formulation) */
   const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" | "small_hill" | "isotropic_elastic" |
-                                       "hypo_hill"; on tri3 meshes "small_J2" | "small_hill_plane_strain"
+                                       "hypo_hill"; on tri3 meshes "small_J2" | "small_hill_plane_strain" |
+                                       "hyper_J2_plane_strain" | "hypo_hill_plane_strain"
                                        (the names of local_residual.cpp:893-933) */
   double stabilization_multiplier;  /* mechanics.cpp:47 */
   int32_t local_max_iters;          /* "nonlinear max iters" of the local residual */
@@ -78,8 +79,8 @@ typedef struct {
   double local_rel_tol;             /* "nonlinear relative tol" */
   int32_t num_params;               /* elastic 4 (E nu cte delta_T), small_J2 6 (E nu K Y cte delta_T),
                                        hyper_J2 8 (E nu Y S D A n K), small_hill / hypo_hill 11 (E nu Y R00 R11 R22
-                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu), small_hill_plane_strain 9
-                                       (E nu Y S D R00 R11 R22 R01) */
+                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu), small_hill_plane_strain /
+                                       hypo_hill_plane_strain 9 (E nu Y S D R00 R11 R22 R01), hyper_J2_plane_strain 6 (E nu K Y Y_inf delta) */
   const double* params;             /* [num_elem_sets][num_params] */
 } c8_model_desc;
 

@@ -1160,6 +1160,124 @@ template <class T> struct SmallHillPlaneStrain : Local<T> {
   T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
 };
 
+// hyper_J2_plane_strain.cpp (2-D: zeta SYM_TENSOR (00,01,11), Ie SCALAR, alpha SCALAR; params E nu K Y Y_inf delta):
+// finite-deformation J2 in plane strain.  The in-plane tensors are completed out of plane where the 3-D quantity is
+// needed: zeta_zz = -tr(zeta) (:153, :256), be_bar_zz = (zeta_zz + Ie) / det(rF)^(2/3) (:154).
+template <class T> struct HyperJ2PlaneStrain : Local<T> {
+  HyperJ2PlaneStrain() { this->ndims = 2; this->nres = 3; this->neq[0] = 3; this->neq[1] = 1; this->neq[2] = 1; this->finish_layout(); }
+  int num_params() const override { return 6; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 5; ++k) xi_pt[k] = 0.; xi_pt[3] = 1.; }  // :119-131
+  bool is_finite_deformation() const override { return true; }
+  // eval_be_bar_plane_strain (:134-156): the 3 x 3 trial tensor, in-plane block + (2,2) entry
+  Tens<T> be_bar(Global<T>& g, Tens<T> const& zeta, T const& Ie) const {
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const F = g.grad_vector_x(0) + I;
+    Tens<T> const F_prev = g.grad_vector_x_prev(0) + I;
+    Tens<T> const rF = F * inverse(F_prev);
+    T const det_rF = det(rF);
+    T const det_rF_13 = cbrt(det_rF);
+    Tens<T> const rF_bar = rF / det_rF_13;
+    Tens<T> const rF_barT = transpose(rF_bar);
+    Tens<T> const be_bar_2D = rF_bar * (zeta + Ie * I) * rF_barT;
+    T const zeta_zz = -trace(zeta);
+    T const be_bar_zz = (zeta_zz + Ie) / (det_rF_13 * det_rF_13);
+    Tens<T> be = be_bar_2D;  // insert_2D_tensor_into_3D
+    be.dim = 3;
+    be(2, 2) = be_bar_zz;
+    return be;
+  }
+  static Tens<T> in_plane(Tens<T> const& t3) {  // extract_2D_tensor_from_3D
+    Tens<T> t;
+    t.dim = 2;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) t(i, j) = t3(i, j);
+    return t;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // :163-223
+    if (std::is_same<T, double>::value) return 0;
+    {
+      Tens<T> const zeta_old = this->sym_tensor_xi_prev(0);
+      T const Ie_old = this->scalar_xi_prev(1);
+      T const alpha_old = this->scalar_xi_prev(2);
+      Tens<T> const bt = be_bar(g, zeta_old, Ie_old);
+      T const Ie_trial = trace(bt) / 3.;
+      Tens<T> const zeta_trial = in_plane(bt) - Ie_trial * eye<T>(2);
+      this->set_sym_tensor_xi_val(0, zeta_trial);
+      this->set_scalar_xi_val(1, val(Ie_trial));
+      this->set_scalar_xi_val(2, val(alpha_old));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :231-325
+    int path = ELASTIC_PATH;
+    double const sqrt_23 = std::sqrt(2. / 3.);
+    double const sqrt_32 = std::sqrt(3. / 2.);
+    T const E = this->params[0], nu = this->params[1], K = this->params[2], Y = this->params[3];
+    T const Y_inf = this->params[4], delta = this->params[5];
+    T const mu = compute_mu(E, nu);
+    Tens<T> const zeta_old = this->sym_tensor_xi_prev(0);
+    T const Ie_old = this->scalar_xi_prev(1);
+    T const alpha_old = this->scalar_xi_prev(2);
+    Tens<T> const zeta = this->sym_tensor_xi(0);
+    T const Ie = this->scalar_xi(1);
+    T const alpha = this->scalar_xi(2);
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const bt = be_bar(g, zeta_old, Ie_old);
+    T const Ie_trial = trace(bt) / 3.;
+    Tens<T> const zeta_trial = in_plane(bt) - Ie_trial * I;
+    Tens<T> zeta_3D = zeta;
+    zeta_3D.dim = 3;
+    zeta_3D(2, 2) = -trace(zeta);
+    Tens<T> const be_bar_3D = zeta_3D + Ie * eye<T>(3);
+    Tens<T> const s_3D = mu * zeta_3D;
+    T const s_mag = norm(s_3D);
+    T const sigma_yield = Y + K * alpha + (Y_inf - Y) * (1. - exp(-(delta * alpha)));
+    T const f = (s_mag - sqrt_23 * sigma_yield) / val(mu);
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    Tens<T> R_zeta;
+    T R_Ie, R_alpha;
+    if (plastic) {
+      Tens<T> const n_2D = mu * zeta / s_mag;
+      T const dgam = sqrt_32 * (alpha - alpha_old);
+      R_zeta = zeta - zeta_trial + 2. * dgam * Ie * n_2D;
+      R_Ie = det(be_bar_3D) - 1.;
+      R_alpha = f;
+    } else {
+      R_zeta = zeta - zeta_trial;
+      R_Ie = Ie - Ie_trial;
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_zeta);
+    this->set_scalar_R(1, R_Ie);
+    this->set_scalar_R(2, R_alpha);
+    return path;
+  }
+  Tens<T> cauchy(Global<T>& g) override {  // :328-337
+    T const p = g.scalar_x(1);
+    return this->dev_cauchy(g) - p * eye<T>(2);
+  }
+  Tens<T> dev_cauchy(Global<T>& g) override {  // :340-351
+    T const mu = compute_mu(this->params[0], this->params[1]);
+    Tens<T> const F = g.grad_vector_x(0) + eye<T>(2);
+    Tens<T> const zeta = this->sym_tensor_xi(0);
+    T const J = det(F);
+    return mu * zeta / J;
+  }
+  T hydro_cauchy(Global<T>& g) override {  // :354-365
+    T const kappa = compute_kappa(this->params[0], this->params[1]);
+    Tens<T> const F = g.grad_vector_x(0) + eye<T>(2);
+    T const J = det(F);
+    return kappa / 2. * (J - 1. / J);
+  }
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
 // minitensor::polar_rotation (Trilinos MiniTensor_LinearAlgebra.t.h, third party, not under /root/reference): the
 // rotation R of F = R U by Newton's iteration X <- (mu X + X^-T / mu) / 2 with Higham's 1-norm/inf-norm scaling
 // ("Functions of Matrices", algorithm 8.20), differentiated through like any other arithmetic.  The converged R is
@@ -1183,7 +1301,7 @@ template <class T> T norm_infinity(Tens<T> const& A) {  // largest absolute row 
 template <class T> Tens<T> polar_rotation(Tens<T> const& A) {
   bool scale = true;
   double const tol_scale = 0.01;
-  double const tol_conv = std::sqrt(3.) * 2.220446049250313e-16;
+  double const tol_conv = std::sqrt((double)A.dim) * 2.220446049250313e-16;  // sqrt(dimension) * machine epsilon
   Tens<T> X = A;
   double gamma = 2.0;
   for (int num_iter = 0; num_iter < 128; ++num_iter) {
@@ -1305,6 +1423,120 @@ template <class T> struct HypoHill : Local<T> {
   }
   Tens<T> dev_cauchy(Global<T>& g) override { return dev(rotated_cauchy(g)); }  // :313-316
   T hydro_cauchy(Global<T>& g) override { return trace(rotated_cauchy(g)) / 3.; }  // :319-322
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
+// hypo_hill_plane_strain.cpp (2-D: TC SYM_TENSOR (00,01,11) = in-plane unrotated Cauchy stress, alpha SCALAR, TC_zz
+// SCALAR; params E nu Y S D R00 R11 R22 R01; R02 = R12 = 1): the hypoelastic rate form of hypo_hill on 2 x 2 kinematics
+// with the out-of-plane stress as an extra unknown; residuals are not scaled by 1/mu here (unlike hypo_hill.cpp)
+template <class T> struct HypoHillPlaneStrain : Local<T> {
+  HypoHillPlaneStrain() { this->ndims = 2; this->nres = 3; this->neq[0] = 3; this->neq[1] = 1; this->neq[2] = 1; this->finish_layout(); }
+  int num_params() const override { return 9; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 5; ++k) xi_pt[k] = 0.; }
+  bool is_finite_deformation() const override { return true; }
+  Tens<T> eval_d(Global<T>& g) const {  // :143-156
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const F = g.grad_vector_x(0) + I;
+    Tens<T> const F_prev = g.grad_vector_x_prev(0) + I;
+    Tens<T> const Finv = inverse(F);
+    Tens<T> const R = polar_rotation(F);
+    Tens<T> const L = (F - F_prev) * Finv;
+    Tens<T> const D = 0.5 * (L + transpose(L));
+    return transpose(R) * D * R;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // :163-224
+    if (std::is_same<T, double>::value) return 0;
+    {
+      double const E = val(this->params[0]), nu = val(this->params[1]);
+      double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+      Tens<T> const I = eye<T>(2);
+      Tens<T> const TC_old = this->sym_tensor_xi_prev(0);
+      T const alpha_old = this->scalar_xi_prev(1);
+      T const TC_zz_old = this->scalar_xi_prev(2);
+      Tens<T> const d = eval_d(g);
+      Tens<T> const TC = TC_old + lambda * trace(d) * I + 2. * mu * d;
+      T const TC_zz = TC_zz_old + lambda * trace(d);
+      this->set_sym_tensor_xi_val(0, TC);
+      this->set_scalar_xi_val(1, val(alpha_old));
+      this->set_scalar_xi_val(2, val(TC_zz));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :232-329
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2], S = this->params[3], D = this->params[4];
+    T const R00 = this->params[5], R11 = this->params[6], R22 = this->params[7], R01 = this->params[8];
+    T const R02 = 1., R12 = 1.;
+    T const lambda = compute_lambda(E, nu);
+    T const mu = compute_mu(E, nu);
+    auto inv2 = [](T const& r) { return 1. / (r * r); };
+    T hp[6];
+    hp[0] = 0.5 * (inv2(R11) + inv2(R22) - inv2(R00));
+    hp[1] = 0.5 * (inv2(R22) + inv2(R00) - inv2(R11));
+    hp[2] = 0.5 * (inv2(R00) + inv2(R11) - inv2(R22));
+    hp[3] = 1.5 * inv2(R12);
+    hp[4] = 1.5 * inv2(R02);
+    hp[5] = 1.5 * inv2(R01);
+    Tens<T> const TC_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1);
+    T const TC_zz_old = this->scalar_xi_prev(2);
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    T const TC_zz = this->scalar_xi(2);
+    Tens<T> s = TC;  // TC_3D
+    s.dim = 3;
+    s(2, 2) = TC_zz;
+    T const d12 = s(1, 1) - s(2, 2), d20 = s(2, 2) - s(0, 0), d01 = s(0, 0) - s(1, 1);
+    T const phi = sqrt(hp[0] * d12 * d12 + hp[1] * d20 * d20 + hp[2] * d01 * d01 +
+                       2. * (hp[3] * s(1, 2) * s(1, 2) + hp[4] * s(0, 2) * s(0, 2) + hp[5] * s(0, 1) * s(0, 1)));
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha)));
+    T const f = (phi - sigma_yield) / val(mu);
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const d = eval_d(g);
+    Tens<T> R_TC = TC - TC_old - lambda * trace(d) * I - 2. * mu * d;
+    T R_TC_zz = TC_zz - TC_zz_old - lambda * trace(d);
+    T R_alpha;
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    if (plastic) {
+      Tens<T> n;  // in-plane part of compute_hill_normal
+      n.dim = 2;
+      n(0, 0) = ((hp[1] + hp[2]) * s(0, 0) - hp[2] * s(1, 1) - hp[1] * s(2, 2)) / phi;
+      n(1, 1) = ((hp[0] + hp[2]) * s(1, 1) - hp[2] * s(0, 0) - hp[0] * s(2, 2)) / phi;
+      n(0, 1) = (hp[5] * s(0, 1)) / phi;
+      n(1, 0) = n(0, 1);
+      T const dgam = alpha - alpha_old;
+      Tens<T> const dp_2D = dgam * n;
+      T const dp_zz = -trace(dp_2D);
+      R_TC = R_TC + 2. * mu * dp_2D;
+      R_alpha = f;
+      R_TC_zz = R_TC_zz + 2. * mu * dp_zz;
+    } else {
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_TC);
+    this->set_scalar_R(1, R_alpha);
+    this->set_scalar_R(2, R_TC_zz);
+    return path;
+  }
+  Tens<T> rotated_cauchy(Global<T>& g) {  // :332-341
+    Tens<T> const F = g.grad_vector_x(0) + eye<T>(2);
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    Tens<T> const R = polar_rotation(F);
+    return R * TC * transpose(R);
+  }
+  Tens<T> cauchy(Global<T>& g) override { return this->dev_cauchy(g) - g.scalar_x(1) * eye<T>(2); }  // :343-352
+  Tens<T> dev_cauchy(Global<T>& g) override { return rotated_cauchy(g) - this->hydro_cauchy(g) * eye<T>(2); }  // :355-362
+  T hydro_cauchy(Global<T>& g) override {  // :365-369
+    Tens<T> const RC = rotated_cauchy(g);
+    return (trace(RC) + this->scalar_xi(2)) / 3.;
+  }
   T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
 };
 
@@ -1467,6 +1699,8 @@ template <class T> Local<T>* make_local(std::string const& type, int ndims = 3) 
   if (ndims == 2) {  // the 2-D decks of the reference that run the 3-D classes on 2 x 2 tensors
     if (type == "small_J2") return new SmallJ2<T>(2);
     if (type == "small_hill_plane_strain") return new SmallHillPlaneStrain<T>();
+    if (type == "hyper_J2_plane_strain") return new HyperJ2PlaneStrain<T>();
+    if (type == "hypo_hill_plane_strain") return new HypoHillPlaneStrain<T>();
     return nullptr;
   }
   if (type == "elastic") return new Elastic<T>();

@@ -218,6 +218,8 @@ static int dispatch_2d(std::string const& model, Call const& c) {
   if (c.staged) return -4;
   if (model == "small_J2") run<E, SmallJ2Plane>(c);
   else if (model == "small_hill_plane_strain") run<E, SmallHillPlaneStrain>(c);
+  else if (model == "hyper_J2_plane_strain") run<E, HyperJ2PlaneStrain>(c);
+  else if (model == "hypo_hill_plane_strain") run<E, HypoHillPlaneStrain>(c);
   else return -2;
   return 0;
 }

@@ -20,10 +20,13 @@ CASES = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("elastic", EL, 0.002
          ("small_hill", HILL, 0.004), ("isotropic_elastic", [1000.0, 0.25], 0.002), ("hypo_hill", HILL, 0.004)]
 MESHES = ["hex8", "tet4"]
 ACTIVE = {"small_J2": [0, 1, 2, 3], "elastic": [0, 1], "hyper_J2": [0, 1, 2, 3, 4, 7], "small_hill": [0, 2, 3, 6, 9, 10], "isotropic_elastic": [0, 1],
-          "hypo_hill": [0, 2, 3, 6, 9, 10], "small_hill_plane_strain": [0, 2, 3, 4, 5, 8]}
+          "hypo_hill": [0, 2, 3, 6, 9, 10], "small_hill_plane_strain": [0, 2, 3, 4, 5, 8], "hyper_J2_plane_strain": [0, 1, 2, 3, 4, 5],
+          "hypo_hill_plane_strain": [0, 2, 3, 4, 5, 8]}
 # 2-D (tri3) cases: the models of the reference's 2-D decks that run on `mechanics` with 2 + 1 equations per node
 HILL_PS = [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.1, 0.9, 1.05]  # E nu Y S D R00 R11 R22 R01
-CASES_2D = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("small_hill_plane_strain", HILL_PS, 0.004)]
+HJ2_PS = [1000.0, 0.25, 100.0, 2.0, 3.0, 40.0]  # E nu K Y Y_inf delta
+CASES_2D = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("small_hill_plane_strain", HILL_PS, 0.004),
+            ("hyper_J2_plane_strain", HJ2_PS, 0.004), ("hypo_hill_plane_strain", HILL_PS, 0.004)]
 
 
 def mesh_2d(kind="structured"):

@@ -162,6 +162,26 @@ def test_notch2D_small_J2_plane_strain_deck_is_small_hill_plane_strain(notch2d):
     assert pr.xi[-1][:, :, 3].max() > 1e-2
 
 
+def test_notch2D_hyper_J2_plane_strain(notch2d):
+    # primal/notch2D_hyper_J2_plane_strain.yaml.in: `mechanics` + `hyper_J2_plane_strain` (finite deformation in 2-D:
+    # PK1 = sigma cof F and the stabilisation with cof^T cof / det F on 2 x 2 tensors), K 100, Y 10, 8 steps; pin :44-45
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "hyper_J2_plane_strain", [1000.0, 0.25, 100.0, 10.0, 0.0, 0.0],
+                   max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.001), max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(8)
+    assert rel(pr.qoi(), 6.5626182813091150e-03) < 1.0e-9, pr.qoi()  # deck tolerance 1e-4; measured 6.5e-12
+    assert pr.xi[-1][:, :, 4].max() > 1e-3
+
+
+def test_notch2D_hypo_J2_plane_strain_deck_is_hypo_hill_plane_strain(notch2d):
+    # primal/notch2D_hypo_J2_plane_strain.yaml.in: `hypo_hill_plane_strain` (:21; R = 1, Y 2 S 10 D 2), 4 steps, ymax pulled
+    # by 0.005 t, Newton 30 iterations; pin :47-48.  2 x 2 polar rotation and the out-of-plane stress as a local unknown.
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "hypo_hill_plane_strain",
+                   [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.005), max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 7.10226176768509899e-03) < 1.0e-8, pr.qoi()  # deck tolerance 1e-4; measured 3.3e-10
+    assert pr.xi[-1][:, :, 3].max() > 1e-2
+
+
 def test_notch2D_small_J2_adjoint_gradient_check(notch2d):
     # adjoint/notch2D_small_J2_adjoint_check.yaml.in: Y 2, 4 steps, tolerances 1e-12, parameters E nu K Y active;
     # the reference runs ROL's checkGradient (13 steps 1e0 .. 1e-12, second-order differences, direction = 0.1 in the
