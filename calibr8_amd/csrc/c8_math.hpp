@@ -117,11 +117,18 @@ C8_HD Dual c8_exp(Dual const& a) {
 C8_HD double c8_exp(double a) { return exp(a); }
 C8_HD Dual c8_abs(Dual const& a) { return a.v >= 0. ? a : Dual(-a.v, -a.d); }
 C8_HD double c8_abs(double a) { return fabs(a); }
-// pow(a, b) with both arguments differentiable (Sacado's rule: zero derivative at a == 0)
+// pow(a, b) with both arguments differentiable (Sacado's rule: zero derivative at a == 0).  Sacado drops the term of an
+// operand that carries no derivatives (an unseeded parameter as exponent: no log of the base, so a negative base -- the
+// hardening variable inside a Newton iteration -- gives a finite derivative); with one tangent per lane that is the
+// operand whose tangent is zero.
 C8_HD Dual c8_pow(Dual const& a, Dual const& b) {
   double const r = pow(a.v, b.v);
   double d = 0.;
-  if (a.v != 0.) d = (b.d * log(a.v) + b.v * a.d / a.v) * r;
+  if (a.v != 0.) {
+    if (b.d != 0.) d += b.d * log(a.v);
+    if (a.d != 0.) d += b.v * a.d / a.v;
+    d *= r;
+  }
   return Dual(r, d);
 }
 C8_HD double c8_pow(double a, double b) { return pow(a, b); }

@@ -174,11 +174,13 @@ inline Fad abs(Fad const& a) {
   for (int i = 0; i < a.n; ++i) r.d[i] = s * a.d[i];
   return r;
 }
-inline Fad pow(Fad const& a, Fad const& b) {
+inline Fad pow(Fad const& a, Fad const& b) {  // Sacado's PowerOp: which formula applies depends on which operands carry derivatives
   Fad r; r.v = std::pow(a.v, b.v); r.n = std::max(a.n, b.n);
   for (int i = 0; i < r.n; ++i) {
     if (a.v == 0.) { r.d[i] = 0.; continue; }
-    r.d[i] = (b.dx(i) * std::log(a.v) + b.v * a.dx(i) / a.v) * r.v;
+    if (a.n > 0 && b.n > 0) r.d[i] = (b.dx(i) * std::log(a.v) + b.v * a.dx(i) / a.v) * r.v;
+    else if (a.n > 0) r.d[i] = b.v * a.dx(i) / a.v * r.v;       // constant exponent (unseeded parameter): no log of the base
+    else r.d[i] = b.dx(i) * std::log(a.v) * r.v;                // constant base
   }
   return r;
 }
@@ -489,6 +491,8 @@ template <class T> struct Local;
 
 template <class T> struct Global {
   int nn = 0, ndofs = 0, ndims = 3;
+  int nres = 2;           // 2: mechanics (u, p); 1: mechanics_plane_stress (u only, mechanics_plane_stress.cpp:24-33)
+  double thickness = 1.;  // mechanics_plane_stress.cpp:22
   int neq[2] = {3, 1};
   int off[2] = {0, 0};
   double stab_mult = 1.;
@@ -499,19 +503,20 @@ template <class T> struct Global {
   Tens<T> F, F_prev, cof_F;
   T det_F;
 
-  void before_elems(int nn_, int ndims_ = 3) {  // global_residual.cpp:102-143; mechanics.cpp:16-55: u has ndims equations
+  void before_elems(int nn_, int ndims_ = 3, int nres_ = 2) {  // global_residual.cpp:102-143; mechanics.cpp:16-55: u has ndims equations
     nn = nn_;
     ndims = ndims_;
+    nres = nres_;
     neq[0] = ndims;
     off[0] = 0;
     off[1] = ndims * nn;
-    ndofs = (ndims + 1) * nn;
+    ndofs = (ndims + (nres == 2 ? 1 : 0)) * nn;
     F.dim = F_prev.dim = cof_F.dim = ndims;
   }
   int dx_idx(int i, int n, int eq) const { return off[i] + n * neq[i] + eq; }
 
   void zero_residual() {  // :150-175
-    for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
+    for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
       R_nodal[i][n][eq] = 0.;
   }
   void gather(double const* u, double const* p, double const* u_prev, double const* p_prev,
@@ -521,6 +526,7 @@ template <class T> struct Global {
         x_nodal[0][n][eq] = u[nodes[n] * ndims + eq];
         x_prev_nodal[0][n][eq] = u_prev[nodes[n] * ndims + eq];
       }
+      if (nres == 1) continue;
       x_nodal[1][n][0] = p[nodes[n]];
       x_prev_nodal[1][n][0] = p_prev[nodes[n]];
     }
@@ -534,7 +540,7 @@ template <class T> struct Global {
     for (int n = 0; n < nn; ++n) { N[n] = N_[n]; for (int d = 0; d < 3; ++d) dN[n][d] = dN_[n][d]; }
   }
   void interpolate() {  // :289-332
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < nres; ++i)
       for (int eq = 0; eq < neq[i]; ++eq) {
         x[i][eq] = x_nodal[i][0][eq] * N[0];
         x_prev[i][eq] = x_prev_nodal[i][0][eq] * N[0];
@@ -543,7 +549,7 @@ template <class T> struct Global {
           x_prev[i][eq] += x_prev_nodal[i][n][eq] * N[n];
         }
       }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < nres; ++i)
       for (int eq = 0; eq < neq[i]; ++eq)
         for (int d = 0; d < ndims; ++d) {
           grad_x[i][eq][d] = x_nodal[i][0][eq] * dN[0][d];
@@ -597,7 +603,7 @@ template <class T> struct Global {
   void evaluate(Local<T>& local, double w, double dv, int ip_set);
 
   void residual_values(double* R) const {  // :380-391
-    for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
+    for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
       R[dx_idx(i, n, eq)] = val(R_nodal[i][n][eq]);
   }
   void jacobian(int nderivs, double* J) const;  // :400-414, row-major ndofs x nderivs
@@ -609,29 +615,29 @@ template <> int Global<double>::seed_wrt_x_prev() { return -1; }
 template <> void Global<double>::unseed_wrt_x_prev() {}
 template <> void Global<double>::jacobian(int, double*) const {}
 template <> int Global<Fad>::seed_wrt_x() {
-  for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
+  for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
     x_nodal[i][n][eq].diff(dx_idx(i, n, eq), ndofs);
   return ndofs;
 }
 template <> void Global<Fad>::unseed_wrt_x() {
-  for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq) {
+  for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq) {
     x_nodal[i][n][eq] = x_nodal[i][n][eq].val();
     R_nodal[i][n][eq].n = 0;  // derivative slots of R are zeroed too (:234)
   }
 }
 template <> int Global<Fad>::seed_wrt_x_prev() {
-  for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
+  for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq)
     x_prev_nodal[i][n][eq].diff(dx_idx(i, n, eq), ndofs);
   return ndofs;
 }
 template <> void Global<Fad>::unseed_wrt_x_prev() {
-  for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq) {
+  for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq) {
     x_prev_nodal[i][n][eq] = x_prev_nodal[i][n][eq].val();
     R_nodal[i][n][eq].n = 0;
   }
 }
 template <> void Global<Fad>::jacobian(int nderivs, double* J) const {
-  for (int i = 0; i < 2; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq) {
+  for (int i = 0; i < nres; ++i) for (int n = 0; n < nn; ++n) for (int eq = 0; eq < neq[i]; ++eq) {
     int const r = dx_idx(i, n, eq);
     for (int j = 0; j < nderivs; ++j) J[r * nderivs + j] = R_nodal[i][n][eq].dx(j);
   }
@@ -645,8 +651,9 @@ template <class T> T compute_kappa(T const& E, T const& nu) { return E / (3. * (
 
 template <class T> struct Local {
   int nres = 0, ndims = 3;
-  int neq[3] = {0, 0, 0};
-  int off[3] = {0, 0, 0};
+  int neq[4] = {0, 0, 0, 0};
+  int off[4] = {0, 0, 0, 0};
+  int z_stretch_idx = -1;  // local_residual.hpp:423,452: the out-of-plane stretch of the finite-deformation plane-stress models
   int ndofs = 0;
   int max_iters = 0;
   double abs_tol = 0., rel_tol = 0.;
@@ -1540,6 +1547,343 @@ template <class T> struct HypoHillPlaneStrain : Local<T> {
   T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
 };
 
+
+// ---------------------------------------------------------------------------
+// Plane-stress family: local models that pair with `mechanics_plane_stress` (one global residual, u).  cauchy() is the
+// in-plane Cauchy stress (sigma_zz = 0 is built into the models); pressure_scale_factor() = 0 is never used.
+// ---------------------------------------------------------------------------
+template <class T> static void hill_params_2d(std::vector<T> const& prm, T* hp) {  // compute_hill_params, yield_functions.hpp:35-50
+  T const R00 = prm[5], R11 = prm[6], R22 = prm[7], R01 = prm[8];
+  T const R02 = 1., R12 = 1.;
+  auto inv2 = [](T const& r) { return 1. / (r * r); };
+  hp[0] = 0.5 * (inv2(R11) + inv2(R22) - inv2(R00));
+  hp[1] = 0.5 * (inv2(R22) + inv2(R00) - inv2(R11));
+  hp[2] = 0.5 * (inv2(R00) + inv2(R11) - inv2(R22));
+  hp[3] = 1.5 * inv2(R12);
+  hp[4] = 1.5 * inv2(R02);
+  hp[5] = 1.5 * inv2(R01);
+}
+template <class T> static T hill_value(Tens<T> const& s, T const* hp) {  // compute_hill_value, :53-72
+  T const d12 = s(1, 1) - s(2, 2), d20 = s(2, 2) - s(0, 0), d01 = s(0, 0) - s(1, 1);
+  return sqrt(hp[0] * d12 * d12 + hp[1] * d20 * d20 + hp[2] * d01 * d01 +
+              2. * (hp[3] * s(1, 2) * s(1, 2) + hp[4] * s(0, 2) * s(0, 2) + hp[5] * s(0, 1) * s(0, 1)));
+}
+template <class T> static Tens<T> hill_normal_2d(Tens<T> const& s, T const* hp, T const& hill) {  // in-plane part of :75-98
+  Tens<T> n;
+  n.dim = 2;
+  n(0, 0) = ((hp[1] + hp[2]) * s(0, 0) - hp[2] * s(1, 1) - hp[1] * s(2, 2)) / hill;
+  n(1, 1) = ((hp[0] + hp[2]) * s(1, 1) - hp[2] * s(0, 0) - hp[0] * s(2, 2)) / hill;
+  n(0, 1) = (hp[5] * s(0, 1)) / hill;
+  n(1, 0) = n(0, 1);
+  return n;
+}
+template <class T> static Tens<T> into_3d(Tens<T> const& t2) { Tens<T> t = t2; t.dim = 3; return t; }  // yield_functions.hpp:9-20
+
+// small_hill_plane_stress.cpp (pstrain SYM_TENSOR (00,01,11), alpha SCALAR; params E nu Y S D R00 R11 R22 R01)
+template <class T> struct SmallHillPlaneStress : Local<T> {
+  SmallHillPlaneStress() { this->ndims = 2; this->nres = 2; this->neq[0] = 3; this->neq[1] = 1; this->finish_layout(); }
+  int num_params() const override { return 9; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 4; ++k) xi_pt[k] = 0.; }  // :112-124
+  bool is_finite_deformation() const override { return false; }
+  int solve_nonlinear(Global<T>& g) override {  // :131-184
+    if (std::is_same<T, double>::value) return 0;
+    this->set_sym_tensor_xi_val(0, this->sym_tensor_xi_prev(0));
+    this->set_scalar_xi_val(1, val(this->scalar_xi_prev(1)));
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :192-275
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2], S = this->params[3], D = this->params[4];
+    T const mu = compute_mu(E, nu);
+    T hp[6];
+    hill_params_2d(this->params, hp);
+    Tens<T> const pstrain_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    Tens<T> const sigma_3D = into_3d(this->cauchy(g));
+    T const hill = hill_value(sigma_3D, hp);
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    Tens<T> R_pstrain;
+    T R_alpha;
+    if (plastic) {
+      Tens<T> const n_2D = hill_normal_2d(sigma_3D, hp, hill);
+      T const dgam = alpha - alpha_old;
+      R_pstrain = pstrain - pstrain_old - dgam * n_2D;
+      R_alpha = f;
+    } else {
+      R_pstrain = pstrain - pstrain_old;
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_pstrain);
+    this->set_scalar_R(1, R_alpha);
+    return path;
+  }
+  T epsilon_zz(Global<T>& g) {  // :318-329
+    T const E = this->params[0], nu = this->params[1];
+    T const mu = compute_mu(E, nu), lambda = compute_lambda(E, nu);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const epsilon = 0.5 * (grad_u + transpose(grad_u));
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    return -(lambda * trace(epsilon) + 2. * mu * trace(pstrain)) / (lambda + 2. * mu);
+  }
+  Tens<T> cauchy(Global<T>& g) override {  // :278-293
+    T const E = this->params[0], nu = this->params[1];
+    T const mu = compute_mu(E, nu), lambda = compute_lambda(E, nu);
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const epsilon = 0.5 * (grad_u + transpose(grad_u));
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    T const epsilon_kk = trace(epsilon) + epsilon_zz(g);
+    return lambda * epsilon_kk * I + 2. * mu * (epsilon - pstrain);
+  }
+  T hydro_cauchy(Global<T>& g) override { return trace(cauchy(g)) / 3.; }                                 // :305-309
+  Tens<T> dev_cauchy(Global<T>& g) override { return cauchy(g) - hydro_cauchy(g) * eye<T>(2); }          // :296-302
+  T pressure_scale_factor() override { return 0.; }
+};
+
+// hyper_J2_plane_stress.cpp (zeta SYM_TENSOR (00,01,11), Ie, lambda_z, alpha SCALAR; params E nu Y S D A n K)
+template <class T> struct HyperJ2PlaneStress : Local<T> {
+  HyperJ2PlaneStress() {
+    this->ndims = 2; this->nres = 4; this->neq[0] = 3; this->neq[1] = this->neq[2] = this->neq[3] = 1;
+    this->z_stretch_idx = 2;
+    this->finish_layout();
+  }
+  int num_params() const override { return 8; }
+  void init_variables(double* xi_pt) const override {  // :121-138
+    for (int k = 0; k < 6; ++k) xi_pt[k] = 0.;
+    xi_pt[3] = 1.;
+    xi_pt[4] = 1.;
+  }
+  bool is_finite_deformation() const override { return true; }
+  // eval_be_bar_plane_stress (:141-169)
+  void be_bar_trial(Global<T>& g, Tens<T> const& zeta_2D, T const& Ie, T const& lambda_z_prev, T const& lambda_z, T& J_2D,
+                    Tens<T>& be_bar) const {
+    Tens<T> const I_2D = eye<T>(2);
+    Tens<T> const I = eye<T>(3);
+    Tens<T> const F_2D = g.grad_vector_x(0) + I_2D;
+    J_2D = det(F_2D);
+    Tens<T> const F_prev_2D = g.grad_vector_x_prev(0) + I_2D;
+    Tens<T> F_3D = into_3d(F_2D), F_prev_3D = into_3d(F_prev_2D);
+    F_3D(2, 2) = lambda_z;
+    F_prev_3D(2, 2) = lambda_z_prev;
+    Tens<T> const rF = F_3D * inverse(F_prev_3D);
+    T const det_rF = det(rF);
+    T const det_rF_13 = cbrt(det_rF);
+    Tens<T> const rF_bar = rF / det_rF_13;
+    Tens<T> const rF_barT = transpose(rF_bar);
+    Tens<T> zeta_3D = into_3d(zeta_2D);
+    zeta_3D(2, 2) = -(zeta_2D(0, 0) + zeta_2D(1, 1));
+    be_bar = rF_bar * (zeta_3D + Ie * I) * rF_barT;
+  }
+  static Tens<T> in_plane(Tens<T> const& t3) {  // extract_2D_tensor_from_3D, yield_functions.hpp:22-33
+    Tens<T> t;
+    t.dim = 2;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) t(i, j) = t3(i, j);
+    return t;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // :176-238
+    if (std::is_same<T, double>::value) return 0;
+    {
+      T J_2D;
+      Tens<T> bt;
+      be_bar_trial(g, this->sym_tensor_xi_prev(0), this->scalar_xi_prev(1), this->scalar_xi_prev(2), this->scalar_xi(2), J_2D, bt);
+      T const Ie_trial = (bt(0, 0) + bt(1, 1) + bt(2, 2)) / 3.;
+      Tens<T> const zeta_trial_3D = bt - Ie_trial * eye<T>(3);
+      this->set_sym_tensor_xi_val(0, in_plane(zeta_trial_3D));
+      this->set_scalar_xi_val(1, val(Ie_trial));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :246-358
+    int path = ELASTIC_PATH;
+    double const sqrt_23 = std::sqrt(2. / 3.), sqrt_32 = std::sqrt(3. / 2.);
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2], S = this->params[3], D = this->params[4];
+    T const A = this->params[5], n = this->params[6], K = this->params[7];
+    T const mu = compute_mu(E, nu), kappa = compute_kappa(E, nu);
+    Tens<T> const zeta_old = this->sym_tensor_xi_prev(0);
+    T const Ie_old = this->scalar_xi_prev(1), lambda_z_old = this->scalar_xi_prev(2), alpha_old = this->scalar_xi_prev(3);
+    Tens<T> const zeta = this->sym_tensor_xi(0);
+    T const Ie = this->scalar_xi(1), lambda_z = this->scalar_xi(2), alpha = this->scalar_xi(3);
+    Tens<T> const I = eye<T>(3);
+    T J_2D;
+    Tens<T> bt;
+    be_bar_trial(g, zeta_old, Ie_old, lambda_z_old, lambda_z, J_2D, bt);
+    T const Ie_trial = (bt(0, 0) + bt(1, 1) + bt(2, 2)) / 3.;
+    Tens<T> const zeta_trial_2D = in_plane(bt - Ie_trial * I);
+    Tens<T> zeta_3D = into_3d(zeta);
+    T const zeta_zz = -(zeta(0, 0) + zeta(1, 1));
+    zeta_3D(2, 2) = zeta_zz;
+    Tens<T> const be_bar = zeta_3D + Ie * I;
+    Tens<T> const s = mu * zeta_3D;
+    T const s_mag = norm(s);
+    double const power_law_offset = 1e-12;
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha))) + A * pow(alpha + power_law_offset, n) + K * alpha;
+    T const f = (s_mag - sqrt_23 * sigma_yield) / val(mu);
+    T const mat_factor = kappa / (2. * mu);
+    T const R_lambda_z = lambda_z - sqrt((1. - zeta_zz / mat_factor) / (J_2D * J_2D));
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    Tens<T> R_zeta;
+    T R_Ie, R_alpha;
+    if (plastic) {
+      Tens<T> const n_2D = mu * zeta / s_mag;
+      T const dgam = sqrt_32 * (alpha - alpha_old);
+      R_zeta = zeta - zeta_trial_2D + 2. * dgam * Ie * n_2D;
+      R_Ie = det(be_bar) - 1.;
+      R_alpha = f;
+    } else {
+      R_zeta = zeta - zeta_trial_2D;
+      R_Ie = Ie - Ie_trial;
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_zeta);
+    this->set_scalar_R(1, R_Ie);
+    this->set_scalar_R(2, R_lambda_z);
+    this->set_scalar_R(3, R_alpha);
+    return path;
+  }
+  T jac(Global<T>& g) { return det(g.grad_vector_x(0) + eye<T>(2)) * this->scalar_xi(2); }
+  Tens<T> cauchy(Global<T>& g) override {  // :361-374
+    T const mu = compute_mu(this->params[0], this->params[1]), kappa = compute_kappa(this->params[0], this->params[1]);
+    T const J = jac(g);
+    return mu * this->sym_tensor_xi(0) / J + (kappa / 2. * (J - 1. / J)) * eye<T>(2);
+  }
+  Tens<T> dev_cauchy(Global<T>& g) override {  // :377-389
+    T const mu = compute_mu(this->params[0], this->params[1]);
+    return mu * this->sym_tensor_xi(0) / jac(g);
+  }
+  T hydro_cauchy(Global<T>& g) override {  // :392-403
+    T const kappa = compute_kappa(this->params[0], this->params[1]);
+    T const J = jac(g);
+    return kappa / 2. * (J - 1. / J);
+  }
+  T pressure_scale_factor() override { return 0.; }
+};
+
+
+// hypo_hill_plane_stress.cpp (TC SYM_TENSOR (00,01,11), alpha, lambda_z SCALAR; params E nu Y S D R00 R11 R22 R01 Q00 Q01
+// Q10 Q11): the material axes Q enter the rate of deformation (:164-177) and the rotated stress (:378-388); the TC rows of
+// the plastic residual are divided by val(mu) on the unforced path only (:303), as the reference does.
+template <class T> struct HypoHillPlaneStress : Local<T> {
+  HypoHillPlaneStress() {
+    this->ndims = 2; this->nres = 3; this->neq[0] = 3; this->neq[1] = 1; this->neq[2] = 1;
+    this->z_stretch_idx = 2;
+    this->finish_layout();
+  }
+  int num_params() const override { return 13; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 5; ++k) xi_pt[k] = 0.; xi_pt[4] = 1.; }  // :138-152
+  bool is_finite_deformation() const override { return true; }
+  Tens<T> compute_Q() const {  // :155-162
+    Tens<T> Q;
+    Q.dim = 2;
+    Q(0, 0) = this->params[9]; Q(0, 1) = this->params[10]; Q(1, 0) = this->params[11]; Q(1, 1) = this->params[12];
+    return Q;
+  }
+  Tens<T> eval_d(Global<T>& g, Tens<T> const& Q) const {  // :164-177
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const F = g.grad_vector_x(0) + I;
+    Tens<T> const F_prev = g.grad_vector_x_prev(0) + I;
+    Tens<T> const Finv = inverse(F);
+    Tens<T> const R = polar_rotation(F);
+    Tens<T> const L = (F - F_prev) * Finv;
+    Tens<T> const D = 0.5 * (L + transpose(L));
+    return transpose(Q) * transpose(R) * D * R * Q;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // :184-248
+    if (std::is_same<T, double>::value) return 0;
+    {
+      double const E = val(this->params[0]), nu = val(this->params[1]);
+      double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+      Tens<T> const I = eye<T>(2);
+      Tens<T> const TC_old = this->sym_tensor_xi_prev(0);
+      T const lambda_z_old = this->scalar_xi_prev(2);
+      Tens<T> const d = eval_d(g, compute_Q());
+      T const d_zz = -lambda * trace(d) / (lambda + 2. * mu);
+      Tens<T> const TC = TC_old + lambda * (trace(d) + d_zz) * I + 2. * mu * d;
+      T const lambda_z = lambda_z_old / (1. - d_zz);
+      this->set_sym_tensor_xi_val(0, TC);
+      this->set_scalar_xi_val(1, val(this->scalar_xi_prev(1)));
+      this->set_scalar_xi_val(2, val(lambda_z));
+    }
+    return this->newton(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :256-375
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2], S = this->params[3], D = this->params[4];
+    T const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+    Tens<T> const TC_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1), lambda_z_old = this->scalar_xi_prev(2);
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1), lambda_z = this->scalar_xi(2);
+    Tens<T> const TC_3D = into_3d(TC);
+    T hp[6];
+    hill_params_2d(this->params, hp);
+    T const phi = hill_value(TC_3D, hp);
+    T const sigma_yield = Y + S * (1. - exp(-(D * alpha)));
+    T const f = (phi - sigma_yield) / val(mu);
+    Tens<T> const I = eye<T>(2);
+    Tens<T> const d = eval_d(g, compute_Q());
+    T const d_zz = -lambda * trace(d) / (lambda + 2. * mu);
+    Tens<T> R_TC = TC - TC_old - lambda * (trace(d) + d_zz) * I - 2. * mu * d;
+    T R_alpha, R_lambda_z;
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    if (plastic) {
+      Tens<T> const n_2D = hill_normal_2d(TC_3D, hp, phi);
+      T const dgam = alpha - alpha_old;
+      Tens<T> const dp_2D = dgam * n_2D;
+      T const dp_zz = -(dp_2D(0, 0) + dp_2D(1, 1));
+      T const corr_dp_zz = 2. * mu * dp_zz / (2. * mu + lambda);  // correction from the return map
+      R_TC(0, 0) = R_TC(0, 0) + (2. * mu * dp_2D(0, 0) - lambda * corr_dp_zz);
+      R_TC(1, 1) = R_TC(1, 1) + (2. * mu * dp_2D(1, 1) - lambda * corr_dp_zz);
+      R_TC(0, 1) = R_TC(0, 1) + 2. * mu * dp_2D(0, 1);
+      if (!force_path) R_TC = R_TC / val(mu);  // :303 (only there)
+      R_alpha = f;
+      R_lambda_z = lambda_z - lambda_z_old / (1. - (d_zz + corr_dp_zz));
+    } else {
+      R_alpha = alpha - alpha_old;
+      R_lambda_z = lambda_z - lambda_z_old / (1. - d_zz);
+    }
+    this->set_sym_tensor_R(0, R_TC);
+    this->set_scalar_R(1, R_alpha);
+    this->set_scalar_R(2, R_lambda_z);
+    return path;
+  }
+  Tens<T> rotated_cauchy(Global<T>& g) {  // :378-388
+    Tens<T> const Q = compute_Q();
+    Tens<T> const F = g.grad_vector_x(0) + eye<T>(2);
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    Tens<T> const R = polar_rotation(F);
+    return R * Q * TC * transpose(Q) * transpose(R);
+  }
+  Tens<T> cauchy(Global<T>& g) override { return rotated_cauchy(g); }                                        // :391-393
+  Tens<T> dev_cauchy(Global<T>& g) override { return rotated_cauchy(g) - hydro_cauchy(g) * eye<T>(2); }   // :396-400
+  T hydro_cauchy(Global<T>& g) override { return trace(rotated_cauchy(g)) / 3.; }                          // :403-405
+  T pressure_scale_factor() override { return 0.; }
+};
+
 // hyper_J2.cpp (zeta SYM_TENSOR, Ie SCALAR, alpha SCALAR; params E nu Y S D A n K)
 template <class T> struct HyperJ2 : Local<T> {
   HyperJ2() { this->nres = 3; this->neq[0] = 6; this->neq[1] = 1; this->neq[2] = 1; this->finish_layout(); }
@@ -1654,6 +1998,21 @@ template <class T> struct HyperJ2 : Local<T> {
 };
 
 template <class T> void Global<T>::evaluate(Local<T>& local, double w, double dv, int ip_set) {
+  if (nres == 1) {  // MechanicsPlaneStress::evaluate, mechanics_plane_stress.cpp:47-95: momentum balance only
+    Tens<T> stress = local.cauchy(*this);
+    if (local.is_finite_deformation()) {  // :66-82
+      Tens<T> const F_invT = transpose(inverse(F));
+      T const z_stretch = local.xi[local.off[local.z_stretch_idx]];
+      stress = z_stretch * det_F * stress * F_invT;
+    }
+    for (int n = 0; n < nn; ++n)
+      for (int i = 0; i < ndims; ++i)
+        for (int j = 0; j < ndims; ++j) {
+          double const dbasis_dx = dN[n][j];
+          R_nodal[0][n][i] += stress(i, j) * dbasis_dx * w * thickness * dv;
+        }
+    return;
+  }
   if (ip_set == 0) {  // evaluate_displacement, mechanics.cpp:116-145
     Tens<T> stress = local.cauchy(*this);
     if (local.is_finite_deformation()) stress = stress * cof_F;  // PK1 = sigma cof(F)
@@ -1701,6 +2060,9 @@ template <class T> Local<T>* make_local(std::string const& type, int ndims = 3) 
     if (type == "small_hill_plane_strain") return new SmallHillPlaneStrain<T>();
     if (type == "hyper_J2_plane_strain") return new HyperJ2PlaneStrain<T>();
     if (type == "hypo_hill_plane_strain") return new HypoHillPlaneStrain<T>();
+    if (type == "small_hill_plane_stress") return new SmallHillPlaneStress<T>();  // these three pair with mechanics_plane_stress
+    if (type == "hyper_J2_plane_stress") return new HyperJ2PlaneStress<T>();
+    if (type == "hypo_hill_plane_stress") return new HypoHillPlaneStress<T>();
     return nullptr;
   }
   if (type == "elastic") return new Elastic<T>();
@@ -1744,6 +2106,8 @@ struct Ctx {
   Local<Fad>* local_f = nullptr;
   int nloc = 0;
   int ngpts = 0;  // coupled points per element = points of the local-state field
+  int nres = 2;           // global residuals: 2 `mechanics`, 1 `mechanics_plane_stress`
+  double thickness = 1.;
   // QoI: 0 = average displacement (avg_disp.cpp), 1 = calibration (calibration.cpp, 3-D form)
   int qoi_kind = 0;
   struct Calib {
@@ -1832,8 +2196,8 @@ static double elem_size(Ctx const& c, double const X[][3]) {  // mechanics.cpp:1
 // scatter_lhs (global_residual.cpp:556-586) and scatter_rhs (:463-479)
 static void scatter_lhs(Ctx const& c, Global<Fad> const& g, int e, double const* dtotal, int ld, LinSys& ls) {
   int const nn = c.kit.nn;
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j) {
+  for (int i = 0; i < g.nres; ++i)
+    for (int j = 0; j < g.nres; ++j) {
       int const dofs_i = g.neq[i] * nn, dofs_j = g.neq[j] * nn;
       double* vals = ls.A[i][j];
       int const* offsets = c.offsets[i][j].data() + (size_t)e * dofs_i * dofs_j;
@@ -1852,7 +2216,7 @@ static void scatter_lhs(Ctx const& c, Global<Fad> const& g, int e, double const*
 template <class T>
 static void scatter_rhs(Ctx const& c, Global<T> const& g, int e, double const* rhs, LinSys& ls) {
   int const nn = c.kit.nn;
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < g.nres; ++i)
     for (int n = 0; n < nn; ++n)
       for (int eq = 0; eq < g.neq[i]; ++eq)
         ls.b[i][c.conn[e * nn + n] * g.neq[i] + eq] += rhs[g.dx_idx(i, n, eq)];
@@ -1866,7 +2230,8 @@ static int forward_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, LinSys& 
                             int e_begin, int e_end, std::vector<int> const* elist = nullptr) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   int nderivs = -1;
   std::vector<double> dC_dxi(64), dC_dx(8 * NMAX), dxi_dx(8 * NMAX), dtotal(NMAX * NMAX), resid(NMAX);
@@ -1928,7 +2293,8 @@ static int forward_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, LinSys& 
 static void global_residual(Ctx& c, Local<double>& local, Fields const& f, LinSys& ls) {
   Global<double> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn, nl = local.ndofs;
   std::vector<double> resid(NMAX);
   for (int es = 0; es < c.nsets; ++es) {
@@ -2077,7 +2443,8 @@ static void adjoint_jacobian(Ctx& c, Local<Fad>& local, Fields const& f, double*
                              LinSys& ls) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   int nderivs = -1;
   std::vector<double> dC_dxi(64), dC_dx(8 * NMAX), dxi_dx(8 * NMAX), dtotal(NMAX * NMAX), dtotalT(NMAX * NMAX),
@@ -2155,7 +2522,8 @@ static void solve_adjoint_local(Ctx& c, Local<Fad>& local, Fields const& f, doub
                                 double* phi, double* g_hist, double* f_hist) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   int nderivs = -1;
   std::vector<double> dC(8 * NMAX), dR(NMAX * NMAX), A(64), rhs(8), phi_pt(8), z(NMAX);
@@ -2169,7 +2537,7 @@ static void solve_adjoint_local(Ctx& c, Local<Fad>& local, Fields const& f, doub
       for (int n = 0; n < nn; ++n) {  // gather_adjoint, global_residual.cpp:423-438
         int const node = c.conn[e * nn + n];
         for (int eq = 0; eq < c.ndims; ++eq) z[global.dx_idx(0, n, eq)] = z_u[node * c.ndims + eq];
-        z[global.dx_idx(1, n, 0)] = z_p[node];
+        if (global.nres == 2) z[global.dx_idx(1, n, 0)] = z_p[node];
       }
       for (int pt = 0; pt < c.kit.npts[0]; ++pt) {
         double const w = c.kit.wts[0][pt];
@@ -2224,7 +2592,8 @@ static void solve_adjoint_local(Ctx& c, Local<Fad>& local, Fields const& f, doub
 // eval_qoi, evaluations.cpp:662-756 (average displacement)
 static double eval_qoi(Ctx& c, Local<double>& local, Fields const& f) {
   Global<double> global;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn;
   double J = 0.;
   for (int es = 0; es < c.nsets; ++es)
@@ -2251,7 +2620,8 @@ static double qoi_preprocess(Ctx& c, Local<double>& local, Fields const& f) {
   if (c.qoi_kind != 1) return 0.;
   Global<double> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn, nl = local.ndofs;
   double total = 0.;
   for (int es = 0; es < c.nsets; ++es) {
@@ -2285,7 +2655,8 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
                          double const* phi, double* grad, double* grad_abs = nullptr) {
   Global<Fad> global;
   global.stab_mult = c.stab_mult;
-  global.before_elems(c.kit.nn, c.ndims);
+  global.before_elems(c.kit.nn, c.ndims, c.nres);
+  global.thickness = c.thickness;
   int const nn = c.kit.nn, nd = global.ndofs, nl = local.ndofs;
   std::vector<double> dC(8 * NMAX), dR(NMAX * NMAX), z(NMAX);
   int gofs = 0;
@@ -2302,7 +2673,7 @@ static void qoi_gradient(Ctx& c, Local<Fad>& local, Fields const& f, double cons
       for (int n = 0; n < nn; ++n) {
         int const node = c.conn[e * nn + n];
         for (int eq = 0; eq < c.ndims; ++eq) z[global.dx_idx(0, n, eq)] = z_u[node * c.ndims + eq];
-        z[global.dx_idx(1, n, 0)] = z_p[node];
+        if (global.nres == 2) z[global.dx_idx(1, n, 0)] = z_p[node];
       }
       for (int ip_set = 0; ip_set < 2; ++ip_set)
         for (int pt = 0; pt < c.kit.npts[ip_set]; ++pt) {
@@ -2375,6 +2746,10 @@ void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, in
     c->set_elems[c->elem_set_of[e]].push_back(e);
   }
   c->local_type = local_type;
+  if (c->local_type.size() > 13 && c->local_type.compare(c->local_type.size() - 13, 13, "_plane_stress") == 0) {
+    c->nres = 1;          // the decks pair these models with `mechanics_plane_stress`: u only,
+    c->kit.npts[1] = 0;   // one ip set (mechanics_plane_stress.cpp:35-38)
+  }
   c->stab_mult = stab_mult;
   c->max_iters = max_iters;
   c->abs_tol = abs_tol;
@@ -2398,6 +2773,8 @@ void* c8o_create(int elem_type, int nnodes, int nelems, double const* coords, in
 void c8o_destroy(void* h) { delete (Ctx*)h; }
 int c8o_nloc(void* h) { return ((Ctx*)h)->nloc; }
 int c8o_ndims(void* h) { return ((Ctx*)h)->ndims; }
+int c8o_nres(void* h) { return ((Ctx*)h)->nres; }
+void c8o_set_thickness(void* h, double t) { ((Ctx*)h)->thickness = t; }
 int c8o_npts(void* h) { return ((Ctx*)h)->ngpts; }
 void c8o_set_params(void* h, double const* params) {
   Ctx* c = (Ctx*)h;

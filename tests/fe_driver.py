@@ -25,9 +25,21 @@ def neq_of(be):
     return [getattr(be, "ndims", 3), 1]
 
 
+def nres_of(be):
+    """global residuals of the backend: 2 (`mechanics`: u, p) or 1 (`mechanics_plane_stress`: u only; the p arrays and
+    the other three blocks exist in the test containers but stay untouched)"""
+    return getattr(be, "nres", 2)
+
+
+def rhs_of(be, ls):
+    return np.concatenate(ls.b[:nres_of(be)])
+
+
 def block_matrix(be, ls):
     n = be.nnodes
     NEQ = neq_of(be)
+    if nres_of(be) == 1:
+        return sp.csr_matrix((ls.A[0][0], be.colidx[0][0], be.rowptr[0][0]), shape=(n * NEQ[0], n * NEQ[0]))
     blocks = [[None, None], [None, None]]
     for i in range(2):
         for j in range(2):
@@ -60,7 +72,7 @@ def apply_dbcs(be, ls, dbcs, x, coords, t, is_adjoint=False):
             row = node * NEQ[i] + bc.eq
             sol = x[i][row]
             v = bc.fn(coords[node, 0], coords[node, 1], coords[node, 2], t)
-            for j in range(2):
+            for j in range(nres_of(be)):
                 rp, ci, vals = be.rowptr[i][j], be.colidx[i][j], ls.A[i][j]
                 lo, hi = rp[row], rp[row + 1]
                 if i == j:
@@ -154,12 +166,13 @@ class Primal:
         x = [self.u[step - 1].copy(), self.p[step - 1].copy()]
         xi = self.xi[step - 1].copy()
         n3 = be.nnodes * neq_of(be)[0]
+        two = nres_of(be) == 2
         it, converged, r0 = 1, False, 1.0
         while it <= self.max_iters and not converged:
             if self._assemble(step, x, xi) != 0:
                 raise RuntimeError("local solve failed at the base point")
-            R = np.concatenate(ls.b)
-            rn = float(np.sqrt(np.sum(ls.b[0] ** 2) + np.sum(ls.b[1] ** 2)))
+            R = rhs_of(be, ls)
+            rn = float(np.sqrt(sum(np.sum(ls.b[i] ** 2) for i in range(nres_of(be)))))
             if it == 1:
                 r0 = rn
             if rn < self.abs_tol or rn / r0 < self.rel_tol:
@@ -168,19 +181,23 @@ class Primal:
             A = block_matrix(be, ls)
             dx = spla.spsolve(A.tocsc(), -R)
             x[0] += dx[:n3]
-            x[1] += dx[n3:]
+            if two:
+                x[1] += dx[n3:]
             if self.use_line_search:
                 psi_0 = 0.5 * rn * rn
                 dpsi_0 = -2.0 * psi_0
                 state = {"applied": 1.0}
+                xi_saved = xi.copy()  # primal.cpp:146-156: every trial warm-starts its local solves from the base state
 
                 def evaluate(alpha):
+                    xi[...] = xi_saved
                     x[0] += (alpha - state["applied"]) * dx[:n3]
-                    x[1] += (alpha - state["applied"]) * dx[n3:]
+                    if two:
+                        x[1] += (alpha - state["applied"]) * dx[n3:]
                     state["applied"] = alpha
                     if self._assemble(step, x, xi) != 0:
                         return False, 0.0, 0.0
-                    Ra = np.concatenate(ls.b)
+                    Ra = rhs_of(be, ls)
                     phi = 0.5 * float(Ra @ Ra)
                     slope = float(Ra @ (block_matrix(be, ls) @ dx))
                     return True, phi, slope
@@ -189,7 +206,8 @@ class Primal:
                 if not ok:
                     raise RuntimeError("line search could not assemble at any trial step")
                 x[0] += (alpha - state["applied"]) * dx[:n3]
-                x[1] += (alpha - state["applied"]) * dx[n3:]
+                if two:
+                    x[1] += (alpha - state["applied"]) * dx[n3:]
             it += 1
         if not converged:
             raise RuntimeError("Newton's method failed in %d iterations" % self.max_iters)
@@ -222,7 +240,7 @@ def adjoint_gradient(primal, nparams):
     """adjoint_objective.cpp:83-95 + adjoint.cpp:76-189: march backwards, return dJ/dp."""
     be = primal.be
     nsteps = len(primal.u) - 1
-    nd = (neq_of(be)[0] + 1) * be.nn
+    nd = (neq_of(be)[0] + (1 if nres_of(be) == 2 else 0)) * be.nn
     g = np.zeros((be.nelems, be.npts, be.nloc))
     f = np.zeros((be.nelems, be.npts, nd))
     grad = np.zeros(nparams)
@@ -237,8 +255,9 @@ def adjoint_gradient(primal, nparams):
         z = [np.zeros(n3), np.zeros(be.nnodes)]
         apply_dbcs(be, ls, primal.dbcs, z, primal.coords, 0.0, is_adjoint=True)
         A = block_matrix(be, ls)
-        zz = spla.spsolve(A.tocsc(), np.concatenate(ls.b))
-        z_u, z_p = np.ascontiguousarray(zz[:n3]), np.ascontiguousarray(zz[n3:])
+        zz = spla.spsolve(A.tocsc(), rhs_of(be, ls))
+        z_u = np.ascontiguousarray(zz[:n3])
+        z_p = np.ascontiguousarray(zz[n3:]) if nres_of(be) == 2 else np.zeros(be.nnodes)
         phi = np.zeros((be.nelems, be.npts, be.nloc))
         be.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
         grad += be.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, nparams)

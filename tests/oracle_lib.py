@@ -41,6 +41,8 @@ def lib():
         L.c8o_destroy.argtypes = [C.c_void_p]
         L.c8o_nloc.argtypes = [C.c_void_p]
         L.c8o_ndims.argtypes = [C.c_void_p]
+        L.c8o_nres.argtypes = [C.c_void_p]
+        L.c8o_set_thickness.argtypes = [C.c_void_p, C.c_double]
         L.c8o_npts.argtypes = [C.c_void_p]
         L.c8o_set_params.argtypes = [C.c_void_p, dp]
         L.c8o_set_active.argtypes = [C.c_void_p, C.c_int, C.c_int, ip]
@@ -124,8 +126,9 @@ class Oracle:
         self.nloc = L.c8o_nloc(self.h)
         self.npts = L.c8o_npts(self.h)
         self.ndims = L.c8o_ndims(self.h)  # 3, or 2 for tri3 (u has ndims equations per node; coords stay [n][3])
+        self.nres = L.c8o_nres(self.h)    # 2 (`mechanics`), or 1 for the *_plane_stress models (`mechanics_plane_stress`)
         self.nn = self.conn.shape[1]
-        self.ndofs = (self.ndims + 1) * self.nn
+        self.ndofs = (self.ndims + (1 if self.nres == 2 else 0)) * self.nn
         self.nnz = [[L.c8o_graph_nnz(self.h, i, j) for j in range(2)] for i in range(2)]
         self.rowptr = [[None, None], [None, None]]
         self.colidx = [[None, None], [None, None]]
@@ -141,6 +144,9 @@ class Oracle:
         if getattr(self, "h", None):
             self.L.c8o_destroy(self.h)
             self.h = None
+
+    def set_thickness(self, t):
+        self.L.c8o_set_thickness(self.h, float(t))
 
     def set_params(self, params):
         self.params = np.ascontiguousarray(np.atleast_2d(np.asarray(params, dtype=np.float64)))

@@ -182,6 +182,42 @@ def test_notch2D_hypo_J2_plane_strain_deck_is_hypo_hill_plane_strain(notch2d):
     assert pr.xi[-1][:, :, 3].max() > 1e-2
 
 
+def test_notch2D_small_J2_plane_stress_deck_is_small_hill_plane_stress(notch2d):
+    # primal/notch2D_small_J2_plane_stress.yaml.in: `mechanics_plane_stress` (ONE global residual, u; one ip set;
+    # mechanics_plane_stress.cpp:24-38) + `small_hill_plane_stress` (:21; R = 1, Y 2 S 10 D 2), 4 steps; pin :47-48
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "small_hill_plane_stress",
+                   [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    assert be.nres == 1 and be.ndims == 2 and be.nloc == 4 and be.ndofs == 6
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.001), max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 2.2831790025047405e-03) < 1.0e-9, pr.qoi()  # deck tolerance 1e-4; measured 4.5e-11
+    assert pr.xi[-1][:, :, 3].max() > 1e-2 and not pr.p[-1].any()
+
+
+def test_notch2D_hyper_J2_plane_stress(notch2d):
+    # primal/notch2D_hyper_J2_plane_stress.yaml.in: `hyper_J2_plane_stress` (zeta, Ie, the out-of-plane stretch lambda_z and
+    # alpha are local unknowns; PK1 = lambda_z J sigma F^-T, mechanics_plane_stress.cpp:66-82), 5 steps of 0.005; pin :46-47.
+    # The local Newton passes through negative alpha, where the power-law term needs Sacado's constant-exponent
+    # derivative rule, and the global line search restores the local state before every trial (primal.cpp:146-156).
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "hyper_J2_plane_stress",
+                   [1000.0, 0.25, 2.0, 10.0, 2.0, 0.0, 0.0, 0.0], max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    assert be.nres == 1 and be.nloc == 6
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.005), max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(5)
+    assert rel(pr.qoi(), 1.7493199283412385e-02) < 1.0e-8, pr.qoi()  # deck tolerance 1e-4; measured 3.4e-10
+    assert pr.xi[-1][:, :, 5].max() > 1e-2 and pr.xi[-1][:, :, 4].min() < 0.99
+
+
+def test_notch2D_hypo_J2_plane_stress_deck_is_hypo_hill_plane_stress(notch2d):
+    # primal/notch2D_hypo_J2_plane_stress.yaml.in: `hypo_hill_plane_stress` (:21; material axes Q = I), 4 steps of 0.005;
+    # pin :51-52
+    be = ol.Oracle(ol.TRI3, notch2d["coords"], notch2d["conn"], "hypo_hill_plane_stress",
+                   [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0], max_iters=500, abs_tol=1e-12,
+                   rel_tol=1e-12)
+    assert be.nres == 1 and be.nloc == 5
+    pr = Primal(be, notch2d["coords"], notch2d_dbcs(notch2d, 0.005), max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 1.1852379652063684e-02) < 1.0e-8, pr.qoi()  # deck tolerance 1e-4; measured 6.7e-10
+    assert pr.xi[-1][:, :, 3].max() > 1e-2
+
+
 def test_notch2D_small_J2_adjoint_gradient_check(notch2d):
     # adjoint/notch2D_small_J2_adjoint_check.yaml.in: Y 2, 4 steps, tolerances 1e-12, parameters E nu K Y active;
     # the reference runs ROL's checkGradient (13 steps 1e0 .. 1e-12, second-order differences, direction = 0.1 in the
