@@ -60,7 +60,8 @@ class LinearSystem:
 
 class Assembler:
     def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0, max_iters=500,
-                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter=None, extra_pairs=None):
+                 abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter=None, extra_pairs=None, global_type=None,
+                 thickness=0.0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("calibr8_amd needs a HIP device: there is no CPU execution path")
@@ -83,8 +84,10 @@ class Assembler:
                          self._es.ctypes.data_as(_l.i32p) if self._es is not None else None,
                          0 if self._xp is None else len(self._xp),
                          None if self._xp is None else self._xp.ctypes.data_as(_l.i32p))
-        mo = _l.ModelDesc(b"mechanics", local_type.encode(), stab_mult, max_iters, abs_tol, rel_tol,
-                          self.params.shape[1], self.params.ctypes.data_as(_l.dp))
+        if global_type is None:  # the pairing of the reference's decks
+            global_type = "mechanics_plane_stress" if local_type.endswith("_plane_stress") else "mechanics"
+        mo = _l.ModelDesc(global_type.encode(), local_type.encode(), stab_mult, max_iters, abs_tol, rel_tol,
+                          self.params.shape[1], self.params.ctypes.data_as(_l.dp), float(thickness))
         h = C.c_void_p()
         _l.check(self.L.c8_create(C.byref(md), C.byref(mo), C.byref(h)))
         self.h = h
@@ -92,8 +95,9 @@ class Assembler:
         self.npts = self.L.c8_num_local_points(h)
         self.ncolors = self.L.c8_num_colors(h)
         self.ndims = self.L.c8_num_dims(h)  # 3, or 2 on tri3 meshes (u arrays are [nnodes * ndims])
+        self.nres = self.L.c8_num_residuals(h)  # 2, or 1 under mechanics_plane_stress: the p arrays / blocks are not used
         self.neq = (self.ndims, 1)
-        self.ndofs = (self.ndims + 1) * self.nn
+        self.ndofs = (self.ndims + (1 if self.nres == 2 else 0)) * self.nn
         self.nnz = [[int(self.L.c8_graph_nnz(h, i, j)) for j in range(2)] for i in range(2)]
         self._graph = None
         if scatter is not None:  # None: the library's default (staged assembly, see c8_set_scatter_mode)

@@ -44,6 +44,10 @@ static int model_id(char const* name, int ndims, int* nloc, int* nparams) {
     if (s == "small_hill_plane_strain") { *nloc = SmallHillPlaneStrain<double>::NLOC; *nparams = SmallHillPlaneStrain<double>::NPARAMS; return MODEL_SMALL_HILL_PLANE_STRAIN; }
     if (s == "hypo_hill_plane_strain") { *nloc = HypoHillPlaneStrain<double>::NLOC; *nparams = HypoHillPlaneStrain<double>::NPARAMS; return MODEL_HYPO_HILL_PLANE_STRAIN; }
     if (s == "hyper_J2_plane_strain") { *nloc = HyperJ2PlaneStrain<double>::NLOC; *nparams = HyperJ2PlaneStrain<double>::NPARAMS; return MODEL_HYPER_J2_PLANE_STRAIN; }
+    // the models of `mechanics_plane_stress` (2 equations per node, no pressure)
+    if (s == "small_hill_plane_stress") { *nloc = SmallHillPlaneStress<double>::NLOC; *nparams = SmallHillPlaneStress<double>::NPARAMS; return MODEL_SMALL_HILL_PLANE_STRESS; }
+    if (s == "hyper_J2_plane_stress") { *nloc = HyperJ2PlaneStress<double>::NLOC; *nparams = HyperJ2PlaneStress<double>::NPARAMS; return MODEL_HYPER_J2_PLANE_STRESS; }
+    if (s == "hypo_hill_plane_stress") { *nloc = HypoHillPlaneStress<double>::NLOC; *nparams = HypoHillPlaneStress<double>::NPARAMS; return MODEL_HYPO_HILL_PLANE_STRESS; }
     return MODEL_NONE;
   }
   if (s == "elastic") { *nloc = Elastic<double>::NLOC; *nparams = Elastic<double>::NPARAMS; return MODEL_ELASTIC; }
@@ -91,11 +95,16 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   int const ndims = md->elem_type == C8_ELEM_TRI3 ? 2 : 3;
   if (md->num_nodes <= 0 || md->num_elems <= 0 || md->num_elem_sets <= 0 || !md->coords || !md->conn)
     return fail(C8_ERR_ARG, "c8_create: empty mesh");
-  if (std::string(mo->global_type ? mo->global_type : "") != "mechanics")
-    return fail(C8_ERR_UNSUPPORTED, "c8_create: global residual must be 'mechanics' (mixed formulation)");
+  std::string const global_type = mo->global_type ? mo->global_type : "";
+  if (global_type != "mechanics" && global_type != "mechanics_plane_stress")
+    return fail(C8_ERR_UNSUPPORTED, "c8_create: global residual must be 'mechanics' (mixed formulation) or 'mechanics_plane_stress'");
   int nloc = 0, nparams = 0;
   int const model = model_id(mo->local_type, ndims, &nloc, &nparams);
   if (model == MODEL_NONE) return fail(C8_ERR_UNSUPPORTED, std::string("c8_create: unknown local residual name") + (ndims == 2 ? " for a 2-D mesh: " : ": ") + (mo->local_type ? mo->local_type : "(null)"));
+  // the plane-stress models carry sigma_zz = 0 and no pressure: they belong to mechanics_plane_stress and only to it
+  if (model_is_plane_stress(model) != (global_type == "mechanics_plane_stress"))
+    return fail(C8_ERR_UNSUPPORTED, "c8_create: 'mechanics_plane_stress' (tri3 meshes) takes the *_plane_stress local residuals, 'mechanics' the others");
+  if (mo->thickness < 0.) return fail(C8_ERR_ARG, "c8_create: negative thickness");
   if (mo->num_params != nparams || !mo->params) return fail(C8_ERR_ARG, "c8_create: wrong number of material parameters for this model");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -129,7 +138,9 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   c->nloc = nloc;
   c->nparams = nparams;
   c->npts0 = (md->elem_type == C8_ELEM_HEX8) ? Elem<C8_HEX8>::NP0 : (md->elem_type == C8_ELEM_TET4 ? Elem<C8_TET4>::NP0 : Elem<C8_TRI3>::NP0);
-  c->ms = ModelSettings{mo->stabilization_multiplier, mo->local_abs_tol, mo->local_rel_tol, mo->local_max_iters};
+  c->ms = ModelSettings{mo->stabilization_multiplier, mo->local_abs_tol, mo->local_rel_tol, mo->local_max_iters,
+                        mo->thickness > 0. ? mo->thickness : 1.};
+  c->nres = model_is_plane_stress(model) ? 1 : 2;
   c->params.assign(mo->params, mo->params + (size_t)md->num_elem_sets * nparams);
   c->active.assign(md->num_elem_sets, std::vector<int32_t>());
   c->active[0].push_back(0);  // default: E of element set 0 (small_J2.cpp:96-98)
@@ -187,13 +198,14 @@ int c8_set_shape_cache(c8_ctx* c, int on) {
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
   stage_release(c);
-  void* bufs[] = {c->d_shape, c->d_cal_faces, c->d_cal_S, c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
+  void* bufs[] = {c->d_shape, c->d_cal_faces, c->d_cal_S, c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_xi_saved, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
 
 int c8_num_local_dofs(const c8_ctx* c) { return c ? c->nloc : C8_ERR_ARG; }
 int c8_num_dims(const c8_ctx* c) { return c ? c->ndims : C8_ERR_ARG; }
+int c8_num_residuals(const c8_ctx* c) { return c ? c->nres : C8_ERR_ARG; }
 int c8_num_local_points(const c8_ctx* c) { return c ? c->npts0 : C8_ERR_ARG; }
 int c8_num_colors(const c8_ctx* c) { return c ? (int)c->color_off.size() - 1 : C8_ERR_ARG; }
 int64_t c8_graph_nnz(const c8_ctx* c, int i, int j) {
@@ -216,6 +228,9 @@ int c8_init_variables(const c8_ctx* c, double* xi) {
       case MODEL_SMALL_HILL_PLANE_STRAIN: SmallHillPlaneStrain<double>::init_variables(x); break;
       case MODEL_HYPER_J2_PLANE_STRAIN: HyperJ2PlaneStrain<double>::init_variables(x); break;
       case MODEL_HYPO_HILL_PLANE_STRAIN: HypoHillPlaneStrain<double>::init_variables(x); break;
+      case MODEL_SMALL_HILL_PLANE_STRESS: SmallHillPlaneStress<double>::init_variables(x); break;
+      case MODEL_HYPER_J2_PLANE_STRESS: HyperJ2PlaneStress<double>::init_variables(x); break;
+      case MODEL_HYPO_HILL_PLANE_STRESS: HypoHillPlaneStress<double>::init_variables(x); break;
       case MODEL_HYPER_J2: HyperJ2<double>::init_variables(x); break;
       case MODEL_SMALL_HILL: SmallHill<double>::init_variables(x); break;
       case MODEL_ISOTROPIC_ELASTIC: IsotropicElastic<double>::init_variables(x); break;
@@ -237,7 +252,8 @@ int c8_set_active_params(c8_ctx* c, int es, int n, const int32_t* idx) {
   if (!c || es < 0 || es >= c->mesh.nsets || n < 0 || (n > 0 && !idx)) return fail(C8_ERR_ARG, "c8_set_active_params: bad argument");
   for (int k = 0; k < n; ++k)
     if (idx[k] < 0 || idx[k] >= c->nparams) return fail(C8_ERR_ARG, "c8_set_active_params: parameter index out of range");
-  if (n > 8) return fail(C8_ERR_ARG, "c8_set_active_params: at most 8 active parameters per element set");
+  if (n > 8 || (c->nres == 1 && n > 6))  // one lane of an element's group per active parameter (six lanes under mechanics_plane_stress)
+    return fail(C8_ERR_ARG, "c8_set_active_params: at most 8 active parameters per element set (6 under mechanics_plane_stress)");
   c->active[es].assign(idx, idx + n);
   return upload_active(c);
 }
@@ -451,9 +467,14 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
   return c8_status(c);
 }
 
-static bool check_state(const c8_state* st) {
-  return st && st->x[0] && st->x[1] && st->x_prev[0] && st->x_prev[1] && st->xi_prev && st->xi;
+// under mechanics_plane_stress (one residual) the entries [1] of a state, a system and an adjoint vector are ignored
+static bool check_state(const c8_ctx* c, const c8_state* st) {
+  if (!st || !st->xi_prev || !st->xi) return false;
+  for (int i = 0; i < c->nres; ++i)
+    if (!st->x[i] || !st->x_prev[i]) return false;
+  return true;
 }
+static bool check_z(const c8_ctx* c, const double* const z[2]) { return z && z[0] && (c->nres == 1 || z[1]); }
 static FieldArgs field_args(const c8_state* st) {
   return FieldArgs{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
 }
@@ -461,10 +482,10 @@ static FieldArgs field_args(const c8_state* st) {
 extern "C" {
 
 int c8_assemble_forward_jacobian(c8_ctx* c, const c8_state* st, const c8_system* sys) {
-  if (!c || !check_state(st) || !sys) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null argument");
-  for (int i = 0; i < 2; ++i) {
+  if (!c || !check_state(c, st) || !sys) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null argument");
+  for (int i = 0; i < c->nres; ++i) {
     if (!sys->b[i]) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null b");
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < c->nres; ++j)
       if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_forward_jacobian: null A block");
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
@@ -485,7 +506,7 @@ int c8_assemble_forward_jacobian_subset(c8_ctx* c, const c8_state* st, const c8_
 }
 
 int c8_assemble_residual(c8_ctx* c, const c8_state* st, const c8_system* sys) {
-  if (!c || !check_state(st) || !sys || !sys->b[0] || !sys->b[1]) return fail(C8_ERR_ARG, "c8_assemble_residual: null argument");
+  if (!c || !check_state(c, st) || !sys || !sys->b[0] || (c->nres == 2 && !sys->b[1])) return fail(C8_ERR_ARG, "c8_assemble_residual: null argument");
   SystemArgs sa{{{nullptr, nullptr}, {nullptr, nullptr}}, {sys->b[0], sys->b[1]}, nullptr, 0};
   // hex8, natural element order with atomic adds (whole mesh, not colour-batched): eight elements per wavefront
   if (c->ks.residual_wave && c->kernel_variant != C8_KERNEL_SLOT && c->scatter_mode != C8_SCATTER_COLORED && !c->subset) {
@@ -499,10 +520,10 @@ int c8_assemble_residual(c8_ctx* c, const c8_state* st, const c8_system* sys) {
 }
 
 int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const double* f, const c8_system* sys) {
-  if (!c || !check_state(st) || !sys || !g || !f) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null argument");
-  for (int i = 0; i < 2; ++i) {
+  if (!c || !check_state(c, st) || !sys || !g || !f) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null argument");
+  for (int i = 0; i < c->nres; ++i) {
     if (!sys->b[i]) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null b");
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < c->nres; ++j)
       if (!sys->A[i][j]) return fail(C8_ERR_ARG, "c8_assemble_adjoint_jacobian: null A block");
   }
   SystemArgs sa{{{sys->A[0][0], sys->A[0][1]}, {sys->A[1][0], sys->A[1][1]}}, {sys->b[0], sys->b[1]}, nullptr, 0};
@@ -525,7 +546,7 @@ int c8_assemble_adjoint_jacobian(c8_ctx* c, const c8_state* st, double* g, const
 }
 
 int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[2], double* phi, double* g, double* f) {
-  if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !g || !f) return fail(C8_ERR_ARG, "c8_solve_adjoint_local: null argument");
+  if (!c || !check_state(c, st) || !check_z(c, z) || !phi || !g || !f) return fail(C8_ERR_ARG, "c8_solve_adjoint_local: null argument");
   AdjointArgs aa{g, f, z[0], z[1], phi, nullptr, c->d_active, c8_qoi_args(c)};
   LaunchFn fn = c->ks.adjoint_local;
   if (c->ks.adjoint_local_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.adjoint_local_wave;
@@ -533,7 +554,7 @@ int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[
 }
 
 int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], const double* phi, double* grad) {
-  if (!c || !check_state(st) || !z || !z[0] || !z[1] || !phi || !grad) return fail(C8_ERR_ARG, "c8_param_gradient: null argument");
+  if (!c || !check_state(c, st) || !check_z(c, z) || !phi || !grad) return fail(C8_ERR_ARG, "c8_param_gradient: null argument");
   int const rcq = c8_qoi_prepare(c, field_args(st));  // preprocess_qoi (evaluations.cpp:780)
   if (rcq) return rcq;
   AdjointArgs aa{nullptr, nullptr, z[0], z[1], const_cast<double*>(phi), grad, c->d_active, c8_qoi_args(c)};
@@ -543,7 +564,7 @@ int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], c
 }
 
 int c8_eval_qoi(c8_ctx* c, const c8_state* st, double* J) {
-  if (!c || !st || !st->x[0] || !st->x[1] || !J) return fail(C8_ERR_ARG, "c8_eval_qoi: null argument");
+  if (!c || !st || !st->x[0] || (c->nres == 2 && !st->x[1]) || !J) return fail(C8_ERR_ARG, "c8_eval_qoi: null argument");
   FieldArgs fa{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
   if (c->qoi_kind == 0) {
     AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, J, c->d_active, c8_qoi_args(c)};

@@ -21,6 +21,7 @@ struct c8_ctx {
   int model = c8::MODEL_NONE;
   int nloc = 0, nparams = 0, npts0 = 0;
   int ndims = 3;                      // 3, or 2 on tri3 meshes: u has ndims equations per node
+  int nres = 2;                       // global residuals: 2 (`mechanics`: u, p), 1 (`mechanics_plane_stress`: u)
   c8::ModelSettings ms{};
   std::vector<double> params;
   std::vector<std::vector<int32_t>> active;
@@ -32,6 +33,7 @@ struct c8_ctx {
   int32_t* d_nodeadj = nullptr;   // node-graph columns (boundary conditions, A x)
   double* d_scalar = nullptr;     // reduction result
   double* d_work[4] = {nullptr, nullptr, nullptr, nullptr};  // Newton driver: dx[2], A dx[2]
+  double* d_xi_saved = nullptr;   // Newton driver: local state at the base point of a line search
   uint8_t* d_pos = nullptr;
   int32_t* d_elem_set = nullptr;
   int32_t* d_order = nullptr;

@@ -49,10 +49,11 @@ struct ModelSettings {
   double stab_mult;
   double abs_tol, rel_tol;
   int max_iters;
+  double thickness = 1.;  // mechanics_plane_stress.cpp:22
 };
 struct FieldArgs {
   double const* u;        // [nnodes][3]
-  double const* p;        // [nnodes]
+  double const* p;        // [nnodes]; not read under mechanics_plane_stress (one residual)
   double const* u_prev;
   double const* p_prev;
   double const* xi_prev;  // [nelems][NP0][NLOC]
@@ -338,13 +339,15 @@ C8_HD void load_element(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& f
       sh.X[n][eq] = mt.coords[(size_t)node * 3 + eq];
       sh.u[n][eq] = fa.u[(size_t)node * E::DIM + eq];
       if (prev) sh.u_prev[n][eq] = fa.u_prev[(size_t)node * E::DIM + eq];
-    } else {
+    }
+    // once per node: by its pressure slot, or (one residual: no such slot) by its first displacement slot
+    if ((E::NRES == 2) ? (i == 1) : (eq == 0)) {
       if (E::DIM == 2) {  // out-of-plane entries of the 3-wide containers
         sh.X[n][2] = 0.;
         sh.u[n][2] = 0.;
         if (prev) sh.u_prev[n][2] = 0.;
       }
-      sh.p[n] = fa.p[node];
+      sh.p[n] = (E::NRES == 2) ? fa.p[node] : 0.;
       sh.node[n] = node;
       if (mt.nodeptr) {
         int const a = mt.nodeptr[node];
@@ -354,6 +357,13 @@ C8_HD void load_element(EX& ex, SH& sh, MeshTables const& mt, FieldArgs const& f
     }
   });
   ex.sync();
+}
+
+// the coupled point fluxes of the element's global residual: `mechanics`, or `mechanics_plane_stress` on Tri3PlaneStress
+template <class E, class T, class Local>
+C8_HD void global_flux(Local const& local, PointState<T> const& g, double h, ModelSettings const& ms, MechFlux<T>& f) {
+  if constexpr (E::NRES == 2) Mechanics::flux_coupled(local, g, h, ms.stab_mult, f);
+  else MechanicsPlaneStress::flux(local, g, ms.thickness, f);
 }
 
 // add the weak-form contribution of one point to lane k's Jacobian column / residual entry
@@ -369,7 +379,8 @@ C8_HD void accumulate_coupled(SH const& sh, int pt, int k, MechFlux<Dual> const&
     Jcol[D * n + 0] += f.Gu.xx.d * d0 + f.Gu.xy.d * d1 + f.Gu.xz.d * d2;
     Jcol[D * n + 1] += f.Gu.yx.d * d0 + f.Gu.yy.d * d1 + f.Gu.yz.d * d2;
     if (D == 3) Jcol[D * n + 2] += f.Gu.zx.d * d0 + f.Gu.zy.d * d1 + f.Gu.zz.d * d2;
-    Jcol[D * E::NN + n] += f.Vp.d * (sh.N[pt][n] * wdv) + f.Gp[0].d * d0 + f.Gp[1].d * d1 + f.Gp[2].d * d2;
+    if constexpr (E::NRES == 2)
+      Jcol[D * E::NN + n] += f.Vp.d * (sh.N[pt][n] * wdv) + f.Gp[0].d * d0 + f.Gp[1].d * d1 + f.Gp[2].d * d2;
   }
   double const d0 = sh.dN[pt][nk][0] * wdv, d1 = sh.dN[pt][nk][1] * wdv, d2 = sh.dN[pt][nk][2] * wdv;
   double const r0 = f.Gu.xx.v * d0 + f.Gu.xy.v * d1 + f.Gu.xz.v * d2;
@@ -464,7 +475,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
   });
   ex.sync();
 
-  for (int ip_set = 0; ip_set < 2; ++ip_set) {
+  for (int ip_set = 0; ip_set < E::NSETS; ++ip_set) {
     if (ip_set == 0 || !E::SAME_POINTS) shape_tables<E>(ex, sh, ip_set);
     int const npts = ip_set == 0 ? E::NP0 : E::NP1;
     for (int pt = 0; pt < npts; ++pt) {
@@ -549,10 +560,10 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
         ex.each([&](int k) {
           Lane& r = ex.lane(k);
           MechFlux<Dual> f;
-          Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+          global_flux<E>(r.m, r.g, sh.h, ms, f);
           accumulate_coupled<E>(sh, pt, k, f, r.Jcol, r.Rk);
         });
-      } else {
+      } else if constexpr (E::NRES == 2) {
         ex.each([&](int k) {
           Lane& r = ex.lane(k);
           interpolate_values<E, Dual, false>(sh, pt, r.g);

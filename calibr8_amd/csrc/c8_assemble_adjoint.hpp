@@ -37,9 +37,11 @@ C8_HD double flux_dot_adjoint(SH const& sh, int pt, MechFlux<Dual> const& f, boo
   C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double const d0 = sh.dN[pt][n][0], d1 = sh.dN[pt][n][1], d2 = sh.dN[pt][n][2];
-    double const zp = sh.z[E::DIM * E::NN + n];
-    zpv += zp * sh.N[pt][n];
-    zpg[0] += zp * d0; zpg[1] += zp * d1; zpg[2] += zp * d2;
+    if constexpr (E::NRES == 2) {
+      double const zp = sh.z[E::DIM * E::NN + n];
+      zpv += zp * sh.N[pt][n];
+      zpg[0] += zp * d0; zpg[1] += zp * d1; zpg[2] += zp * d2;
+    }
     C8_UNROLL
     for (int i = 0; i < E::DIM; ++i) {
       double const zu = sh.z[E::DIM * n + i];
@@ -94,7 +96,7 @@ C8_HD void residual_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, Mesh
     if (k == 0) sh.h = elem_size<E>(sh);
   });
   ex.sync();
-  for (int ip_set = 0; ip_set < 2; ++ip_set) {
+  for (int ip_set = 0; ip_set < E::NSETS; ++ip_set) {
     if (ip_set == 0 || !E::SAME_POINTS) shape_tables<E>(ex, sh, ip_set);
     int const npts = ip_set == 0 ? E::NP0 : E::NP1;
     for (int pt = 0; pt < npts; ++pt) {
@@ -106,9 +108,9 @@ C8_HD void residual_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, Mesh
           C8_UNROLL
           for (int j = 0; j < NL; ++j) { r.m.xi[j] = fa.xi[q + j]; r.m.xi_prev[j] = fa.xi_prev[q + j]; }
           MechFlux<double> f;
-          Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+          global_flux<E>(r.m, r.g, sh.h, ms, f);
           r.Rk += residual_entry<E>(sh, pt, k, f);
-        } else {
+        } else if constexpr (E::NRES == 2) {
           interpolate_values<E, double, false>(sh, pt, r.g);
           int ik, nk, eqk;
           slot_to_dof<E>(k, ik, nk, eqk);
@@ -148,7 +150,7 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
     if (k == 0) sh.h = elem_size<E>(sh);
   });
   ex.sync();
-  for (int ip_set = 0; ip_set < 2; ++ip_set) {
+  for (int ip_set = 0; ip_set < E::NSETS; ++ip_set) {
     if (ip_set == 0 || !E::SAME_POINTS) shape_tables<E>(ex, sh, ip_set);
     int const npts = ip_set == 0 ? E::NP0 : E::NP1;
     for (int pt = 0; pt < npts; ++pt) {
@@ -193,7 +195,7 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           C8_UNROLL
           for (int j = 0; j < NL; ++j) r.m.xi[j].d = r.b[j];
           MechFlux<Dual> f;
-          Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+          global_flux<E>(r.m, r.g, sh.h, ms, f);
           double dummy = 0.;
           accumulate_coupled<E>(sh, pt, k, f, r.Jcol, dummy);
           C8_UNROLL
@@ -220,7 +222,7 @@ C8_HD void adjoint_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           for (int j = 0; j < NL; ++j) s += r.b[j] * sh.vec[j];
           r.rhs += s;
         });
-      } else {
+      } else if constexpr (E::NRES == 2) {
         ex.each([&](int k) {
           auto& r = ex.lane(k);
           interpolate_values<E, Dual, false>(sh, pt, r.g);
@@ -300,7 +302,7 @@ C8_HD void adjoint_local_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh,
         r.m.R[j] = Dual(0.);
       }
       MechFlux<Dual> f;
-      Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+      global_flux<E>(r.m, r.g, sh.h, ms, f);
       double const dRz = flux_dot_adjoint<E>(sh, pt, f, true);
       r.m.evaluate(r.g, ms.abs_tol);
       if (k < NL) {
@@ -387,7 +389,7 @@ C8_HD void param_gradient_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh
     if (k == 0) sh.h = elem_size<E>(sh);
   });
   ex.sync();
-  for (int ip_set = 0; ip_set < 2; ++ip_set) {
+  for (int ip_set = 0; ip_set < E::NSETS; ++ip_set) {
     if (ip_set == 0 || !E::SAME_POINTS) shape_tables<E>(ex, sh, ip_set);
     int const npts = ip_set == 0 ? E::NP0 : E::NP1;
     for (int pt = 0; pt < npts; ++pt) {
@@ -409,10 +411,10 @@ C8_HD void param_gradient_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh
           for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];  // (dC/dp)^T phi (:864-866)
           s += QoI::evaluate(r.g, r.m, sh.wdv[pt], aa.qoi, qp).d;               // dJ/dp (:869-871)
           MechFlux<Dual> f;
-          Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
+          global_flux<E>(r.m, r.g, sh.h, ms, f);
           s += flux_dot_adjoint<E>(sh, pt, f, true);                         // (dR/dp)^T z (:883-886)
           r.acc += s;
-        } else {
+        } else if constexpr (E::NRES == 2) {
           interpolate_values<E, Dual, false>(sh, pt, r.g);
           MechFlux<Dual> f;
           f.Vp = Mechanics::flux_pressure(r.m, r.g);

@@ -19,6 +19,8 @@ template <int ET> struct Elem;
 
 template <> struct Elem<C8_HEX8> {
   static constexpr int TYPE = C8_HEX8;
+  static constexpr int NRES = 2;       // global residuals of `mechanics`: u and p; two ip sets
+  static constexpr int NSETS = 2;
   static constexpr int DIM = 3;
   static constexpr int NN = 8;         // nodes
   static constexpr int NDOF = 32;      // 3*NN + NN
@@ -61,6 +63,8 @@ template <> struct Elem<C8_HEX8> {
 
 template <> struct Elem<C8_TET4> {
   static constexpr int TYPE = C8_TET4;
+  static constexpr int NRES = 2;       // global residuals of `mechanics`: u and p; two ip sets
+  static constexpr int NSETS = 2;
   static constexpr int DIM = 3;
   static constexpr int NN = 4;
   static constexpr int NDOF = 16;
@@ -97,6 +101,8 @@ template <> struct Elem<C8_TET4> {
 
 template <> struct Elem<C8_TRI3> {
   static constexpr int TYPE = C8_TRI3;
+  static constexpr int NRES = 2;       // global residuals of `mechanics`: u and p; two ip sets
+  static constexpr int NSETS = 2;
   static constexpr int DIM = 2;
   static constexpr int NN = 3;
   static constexpr int NDOF = 9;       // 2*NN + NN
@@ -123,6 +129,15 @@ template <> struct Elem<C8_TRI3> {
     g[2] = 0.;
   }
   C8_HD static void edge(int e, int& a, int& b) { a = e; b = (e + 1) % 3; }  // (0,1)(1,2)(2,0)
+};
+
+// tri3 under `mechanics_plane_stress` (mechanics_plane_stress.cpp:24-38): ONE global residual (u, 2 equations per node),
+// one ip set (order 1); element DOFs are the six displacement slots, so a wavefront carries ten lane groups
+struct Tri3PlaneStress : Elem<C8_TRI3> {
+  static constexpr int NRES = 1;
+  static constexpr int NSETS = 1;
+  static constexpr int NDOF = 6;
+  static constexpr int NP1 = 0;
 };
 
 // which residual / node / equation an element DOF slot addresses (dx_idx inverse)

@@ -515,13 +515,17 @@ static KernelSet kernel_set_2d(int model) {
     case MODEL_SMALL_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, SmallHillPlaneStrain>();
     case MODEL_HYPER_J2_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, HyperJ2PlaneStrain>();
     case MODEL_HYPO_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, HypoHillPlaneStrain>();
+    // `mechanics_plane_stress`: one residual, six element DOFs
+    case MODEL_SMALL_HILL_PLANE_STRESS: return kernel_set<Tri3PlaneStress, SmallHillPlaneStress>();
+    case MODEL_HYPER_J2_PLANE_STRESS: return kernel_set<Tri3PlaneStress, HyperJ2PlaneStress>();
+    case MODEL_HYPO_HILL_PLANE_STRESS: return kernel_set<Tri3PlaneStress, HypoHillPlaneStress>();
   }
   return KernelSet{};
 }
 
 KernelSet get_kernels(int elem_type, int model) {
   if (elem_type == C8_TRI3) return kernel_set_2d(model);
-  if (model == MODEL_SMALL_HILL_PLANE_STRAIN || model == MODEL_HYPER_J2_PLANE_STRAIN || model == MODEL_HYPO_HILL_PLANE_STRAIN) return KernelSet{};
+  if (model >= MODEL_SMALL_HILL_PLANE_STRAIN) return KernelSet{};  // the plane models exist on 2-D meshes only
   if (elem_type == C8_HEX8) return kernel_set_for<Elem<C8_HEX8>>(model);
   if (elem_type == C8_TET4) return kernel_set_for<Elem<C8_TET4>>(model);
   return KernelSet{};

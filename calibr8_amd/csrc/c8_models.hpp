@@ -632,6 +632,302 @@ template <class T> struct HypoHillPlaneStrain {
   }
 };
 
+
+// =====================================================================================================================
+// Plane-stress family: the local models that pair with `mechanics_plane_stress` (one global residual, u).  cauchy() is
+// the in-plane Cauchy stress -- sigma_zz = 0 is built into the models --; there is no pressure unknown, so g.p is never
+// read and pressure_scale_factor() (0 in the reference) is never used.
+// =====================================================================================================================
+
+// compute_hill_params / compute_hill_value / in-plane compute_hill_normal with R02 = R12 = 1 (yield_functions.hpp:35-98)
+// on a 2-D stress completed by s_zz; params[5..8] = R00 R11 R22 R01
+template <class T> struct HillPlane {
+  T F, G, H, N;
+  C8_HD explicit HillPlane(T const* params) {
+    auto inv2 = [](T const& r) { return 1. / (r * r); };
+    T const i00 = inv2(params[5]), i11 = inv2(params[6]), i22 = inv2(params[7]);
+    F = 0.5 * (i11 + i22 - i00);
+    G = 0.5 * (i22 + i00 - i11);
+    H = 0.5 * (i00 + i11 - i22);
+    N = 1.5 * inv2(params[8]);
+  }
+  C8_HD T value(Tens3<T> const& s, T const& s_zz) const {
+    T const d12 = s.yy - s_zz, d20 = s_zz - s.xx, d01 = s.xx - s.yy;
+    return c8_sqrt(F * d12 * d12 + G * d20 * d20 + H * d01 * d01 + 2. * (N * s.xy * s.xy));
+  }
+  C8_HD Tens3<T> normal(Tens3<T> const& s, T const& s_zz, T const& hill) const {
+    Tens3<T> n = scale(0., s);
+    n.xx = ((G + H) * s.xx - H * s.yy - G * s_zz) / hill;
+    n.yy = ((F + H) * s.yy - H * s.xx - F * s_zz) / hill;
+    n.xy = n.yx = N * s.xy / hill;
+    return n;
+  }
+};
+
+// ---- small_hill_plane_stress.cpp: small strain, eps_zz eliminated by sigma_zz = 0 (:318-329) ----------------------------
+template <class T> struct SmallHillPlaneStress {
+  static constexpr int NLOC = 4, NPARAMS = 9;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
+  T params[NPARAMS];  // E nu Y S D R00 R11 R22 R01  (small_hill_plane_stress.cpp:70-78)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain (00,01,11), alpha
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD void initial_guess(PointState<T> const&) {  // :138-146
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(xi_prev[k]));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :278-293 with epsilon_zz of :318-329
+    T const mu = compute_mu(params[0], params[1]);
+    T const lambda = compute_lambda(params[0], params[1]);
+    Tens3<T> const eps = small_strain(g.grad_u);
+    Tens3<T> const ps = sym_dim<2>(xi);
+    T const eps_zz = -(lambda * trace(eps) + 2. * mu * trace(ps)) / (lambda + 2. * mu);
+    T const eps_kk = trace(eps) + eps_zz;
+    return minus_s_eye<2>(scale(2. * mu, eps - ps), -(lambda * eps_kk));
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const { return trace(cauchy(g)) / 3.; }  // :305-309
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :296-302
+    Tens3<T> const c = cauchy(g);
+    return minus_s_eye<2>(c, trace(c) / 3.);
+  }
+  C8_HD T pressure_scale_factor() const { return T(0.); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :192-275
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[3], D = params[4];
+    HillPlane<T> const hp(params);
+    T const alpha = xi[3], alpha_old = xi_prev[3];
+    Tens3<T> const sigma = cauchy(g);
+    T const zero = T(0.);
+    T const hill = hp.value(sigma, zero);
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (hill - sigma_yield) / val(mu);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = alpha - alpha_old;
+      pack_sym_dim<2>(sym_dim<2>(xi) - sym_dim<2>(xi_prev) - scale(dgam, hp.normal(sigma, zero, hill)), R);
+      R[3] = f;
+    } else {
+      C8_UNROLL
+      for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
+    }
+    return path;
+  }
+};
+
+// ---- hyper_J2_plane_stress.cpp: finite-deformation J2; local unknowns zeta (00,01,11), Ie, the out-of-plane stretch
+//      lambda_z and alpha.  F_3D = [F_2D, lambda_z], zeta_zz = -tr(zeta); lambda_z closes sigma_zz = 0 (:302-304) --------
+template <class T> struct HyperJ2PlaneStress {
+  static constexpr int NLOC = 6, NPARAMS = 8;
+  static constexpr int Z_STRETCH = 4;  // m_z_stretch_idx (:60): position of lambda_z in xi
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  using Trial = NoTrial;  // the trial state depends on the unknown lambda_z: nothing to cache over the Newton iteration
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
+  T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2_plane_stress.cpp:80-87)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];
+  C8_HD static void init_variables(double* xi0) {  // :121-138
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) xi0[k] = 0.;
+    xi0[3] = 1.;
+    xi0[4] = 1.;
+  }
+  // eval_be_bar_plane_stress (:141-169) from the previous zeta, Ie, lambda_z and the current lambda_z; returns the trial
+  // values Ie_trial and zeta_trial (00,01,11) and det F_2D
+  C8_HD void trial_state(PointState<T> const& g, T const& lambda_z, T* zeta_trial, T& Ie_trial, T& J_2D) const {
+    Tens3<T> F = g.grad_u + eye3<T>();
+    J_2D = det(F);  // F_zz = 1 here: the 2 x 2 determinant
+    Tens3<T> F_prev = g.grad_u_prev + eye3<T>();
+    F.zz = lambda_z;
+    F_prev.zz = xi_prev[4];
+    Tens3<T> const rF = matmul(F, inverse(F_prev));
+    T const det_rF_13 = c8_cbrt(det(rF));
+    Tens3<T> const rF_bar = scale(1. / det_rF_13, rF);
+    Tens3<T> inner = sym_dim<2>(xi_prev);  // zeta_3D + Ie I(3) of the previous step
+    inner.zz = -(xi_prev[0] + xi_prev[2]);
+    inner.xx = inner.xx + xi_prev[3];
+    inner.yy = inner.yy + xi_prev[3];
+    inner.zz = inner.zz + xi_prev[3];
+    Tens3<T> const be = matmul(matmul(rF_bar, inner), transpose(rF_bar));
+    Ie_trial = trace(be) / 3.;
+    zeta_trial[0] = be.xx - Ie_trial;
+    zeta_trial[1] = be.xy;
+    zeta_trial[2] = be.yy - Ie_trial;
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // :183-201: zeta and Ie from the trial state; lambda_z, alpha stay
+    T zt[3], Ie_t, J_2D;
+    trial_state(g, xi[4], zt, Ie_t, J_2D);
+    C8_UNROLL
+    for (int k = 0; k < 3; ++k) set_val(xi[k], val(zt[k]));
+    set_val(xi[3], val(Ie_t));
+  }
+  C8_HD T jac(PointState<T> const& g) const { return det(g.grad_u + eye3<T>()) * xi[4]; }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :377-389
+    return scale(compute_mu(params[0], params[1]) / jac(g), sym_dim<2>(xi));
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const {  // :392-403
+    T const J = jac(g);
+    return (compute_kappa(params[0], params[1]) * 0.5) * (J - 1. / J);
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :361-374
+    T const J = jac(g);
+    T const kappa = compute_kappa(params[0], params[1]);
+    return minus_s_eye<2>(scale(compute_mu(params[0], params[1]) / J, sym_dim<2>(xi)), -((kappa * 0.5) * (J - 1. / J)));
+  }
+  C8_HD T pressure_scale_factor() const { return T(0.); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :246-358
+    double const sqrt_23 = 0.81649658092772603273;
+    double const sqrt_32 = 1.22474487139158904910;
+    T const mu = compute_mu(params[0], params[1]), kappa = compute_kappa(params[0], params[1]);
+    T const Y = params[2], S = params[3], D = params[4], A = params[5], nexp = params[6], K = params[7];
+    T const Ie = xi[3], lambda_z = xi[4], alpha = xi[5], alpha_old = xi_prev[5];
+    T zt[3], Ie_trial, J_2D;
+    trial_state(g, lambda_z, zt, Ie_trial, J_2D);
+    Tens3<T> const zeta = sym_dim<2>(xi);
+    T const zeta_zz = -(xi[0] + xi[2]);
+    Tens3<T> s3 = scale(mu, zeta);  // s = mu zeta_3D
+    s3.zz = mu * zeta_zz;
+    T const s_mag = norm(s3);
+    double const power_law_offset = 1e-12;
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha))) + A * c8_pow(alpha + power_law_offset, nexp) + K * alpha;
+    T const f = (s_mag - sqrt_23 * sigma_yield) / val(mu);
+    T const mat_factor = kappa / (2. * mu);
+    R[4] = lambda_z - c8_sqrt((1. - zeta_zz / mat_factor) / (J_2D * J_2D));
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    Tens3<T> Rz = zeta - sym_dim<2>(zt);
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = sqrt_32 * (alpha - alpha_old);
+      T const c = (2. * dgam) * Ie * mu / s_mag;  // 2 dgam Ie n_2D, n_2D = mu zeta / |s|
+      Rz = Rz + scale(c, zeta);
+      Tens3<T> be = zeta;  // be_bar = zeta_3D + Ie I(3)
+      be.xx = be.xx + Ie; be.yy = be.yy + Ie; be.zz = zeta_zz + Ie;
+      R[3] = det(be) - 1.;
+      R[5] = f;
+    } else {
+      R[3] = Ie - Ie_trial;
+      R[5] = alpha - alpha_old;
+    }
+    pack_sym_dim<2>(Rz, R);
+    return path;
+  }
+};
+
+// ---- hypo_hill_plane_stress.cpp: hypoelastic rate form, unrotated in-plane Cauchy stress TC (00,01,11), alpha and the
+//      out-of-plane stretch lambda_z; the material axes Q rotate the rate of deformation (:164-177) and the stress
+//      (:378-388).  The TC rows of the plastic residual are divided by val(mu) on the unforced path only (:303). ---------
+template <class T> struct HypoHillPlaneStress {
+  static constexpr int NLOC = 5, NPARAMS = 13;
+  static constexpr int Z_STRETCH = 4;  // m_z_stretch_idx (:72)
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  T params[NPARAMS];  // E nu Y S D R00 R11 R22 R01 Q00 Q01 Q10 Q11  (hypo_hill_plane_stress.cpp:92-104)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];
+  C8_HD static void init_variables(double* xi0) {  // :138-152
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) xi0[k] = 0.;
+    xi0[4] = 1.;
+  }
+  C8_HD Tens3<T> material_axes() const {  // compute_Q :155-162
+    Tens3<T> Q = scale(0., eye3<T>());
+    Q.xx = params[9]; Q.xy = params[10]; Q.yx = params[11]; Q.yy = params[12];
+    return Q;
+  }
+  // d = Q^T R^T sym((F - F_prev) F^-1) R Q depends on F and F_prev only (eval_d :164-177)
+  struct Trial { T d[3]; };
+  C8_HD Trial trial(PointState<T> const& g) const {
+    Tens3<T> const I = eye3<T>();
+    Tens3<T> const F = g.grad_u + I;
+    Tens3<T> const F_prev = g.grad_u_prev + I;
+    Tens3<T> const Rot = polar_rotation(F);
+    Tens3<T> const L = matmul(F - F_prev, inverse(F));
+    Tens3<T> const D = scale(0.5, L + transpose(L));
+    Tens3<T> const Q = material_axes();
+    Trial t;
+    pack_sym_dim<2>(matmul(matmul(matmul(matmul(transpose(Q), transpose(Rot)), D), Rot), Q), t.d);
+    return t;
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // :191-211: elastic predictor, values only
+    double const E = val(params[0]), nu = val(params[1]);
+    double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+    Trial const t = trial(g);
+    double const tr_d = val(t.d[0]) + val(t.d[2]);
+    double const d_zz = -lambda * tr_d / (lambda + 2. * mu);
+    double const ltr = lambda * (tr_d + d_zz);
+    set_val(xi[0], val(xi_prev[0]) + ltr + 2. * mu * val(t.d[0]));
+    set_val(xi[1], val(xi_prev[1]) + 2. * mu * val(t.d[1]));
+    set_val(xi[2], val(xi_prev[2]) + ltr + 2. * mu * val(t.d[2]));
+    set_val(xi[3], val(xi_prev[3]));
+    set_val(xi[4], val(xi_prev[4]) / (1. - d_zz));
+  }
+  C8_HD Tens3<T> rotated_cauchy(PointState<T> const& g) const {  // :378-388
+    Tens3<T> const Rot = polar_rotation(g.grad_u + eye3<T>());
+    Tens3<T> const Q = material_axes();
+    return matmul(matmul(matmul(matmul(Rot, Q), sym_dim<2>(xi)), transpose(Q)), transpose(Rot));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const { return rotated_cauchy(g); }                  // :391-393
+  C8_HD T hydro_cauchy(PointState<T> const& g) const { return trace(rotated_cauchy(g)) / 3.; }       // :403-405
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {                                          // :396-400
+    Tens3<T> const RC = rotated_cauchy(g);
+    return minus_s_eye<2>(RC, trace(RC) / 3.);
+  }
+  C8_HD T pressure_scale_factor() const { return T(0.); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {
+    return evaluate(g, abs_tol, trial(g), force_path, path_in);
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const& tr, bool force_path = false, int path_in = 0) {  // :256-375
+    T const lambda = compute_lambda(params[0], params[1]);
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], S = params[3], D = params[4];
+    HillPlane<T> const hp(params);
+    T const alpha = xi[3], alpha_old = xi_prev[3], lambda_z = xi[4], lambda_z_old = xi_prev[4];
+    Tens3<T> const TC = sym_dim<2>(xi);
+    T const zero = T(0.);
+    T const phi = hp.value(TC, zero);
+    T const sigma_yield = Y + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (phi - sigma_yield) / val(mu);
+    Tens3<T> const d = sym_dim<2>(tr.d);
+    T const d_zz = -(lambda * trace(d)) / (lambda + 2. * mu);
+    Tens3<T> Rt = minus_s_eye<2>(TC - sym_dim<2>(xi_prev), lambda * (trace(d) + d_zz)) - scale(2. * mu, d);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = alpha - alpha_old;
+      Tens3<T> const dp = scale(dgam, hp.normal(TC, zero, phi));
+      T const dp_zz = -(dp.xx + dp.yy);
+      T const corr_dp_zz = (2. * mu) * dp_zz / (2. * mu + lambda);  // correction from the return map
+      Rt.xx = Rt.xx + ((2. * mu) * dp.xx - lambda * corr_dp_zz);
+      Rt.yy = Rt.yy + ((2. * mu) * dp.yy - lambda * corr_dp_zz);
+      Rt.xy = Rt.xy + (2. * mu) * dp.xy;
+      Rt.yx = Rt.xy;
+      if (!force_path) Rt = scale(1. / val(mu), Rt);
+      R[3] = f;
+      R[4] = lambda_z - lambda_z_old / (1. - (d_zz + corr_dp_zz));
+    } else {
+      R[3] = alpha - alpha_old;
+      R[4] = lambda_z - lambda_z_old / (1. - d_zz);
+    }
+    pack_sym_dim<2>(Rt, R);
+    return path;
+  }
+};
+
 // ---- hyper_J2.cpp -------------------------------------------------------------
 template <class T> struct HyperJ2 {
   static constexpr int NLOC = 8, NPARAMS = 8;
@@ -797,6 +1093,25 @@ struct Mechanics {
   template <class T, class Local>
   C8_HD static T flux_pressure(Local const& local, PointState<T> const& g) {  // :215-223
     return -(g.p / local.pressure_scale_factor());
+  }
+};
+
+// MechanicsPlaneStress::evaluate (mechanics_plane_stress.cpp:47-95): the momentum balance with the local model's in-plane
+// Cauchy stress; under finite deformation PK1 = lambda_z J sigma F^-T with the model's out-of-plane stretch (:66-82);
+// everything times the thickness (:90).  No pressure residual.
+struct MechanicsPlaneStress {
+  template <class T, class Local>
+  C8_HD static void flux(Local const& local, PointState<T> const& g, double thickness, MechFlux<T>& f) {
+    Tens3<T> stress = local.cauchy(g);
+    if constexpr (Local::FINITE_DEF) {
+      Tens3<T> const F = g.grad_u + eye3<T>();  // F_zz = 1: determinant and inverse are the 2 x 2 ones
+      Tens3<T> const F_invT = transpose(inverse(F));
+      T const J = det(F);
+      stress = matmul(scale(local.xi[Local::Z_STRETCH] * J, stress), F_invT);
+    }
+    f.Gu = scale(thickness, stress);
+    f.Vp = T(0.);
+    f.Gp[0] = f.Gp[1] = f.Gp[2] = T(0.);
   }
 };
 

@@ -22,7 +22,7 @@ __host__ __device__ inline int neq_of(int i, int ndims) { return i == 0 ? ndims 
 // dbcs.cpp:68-118: one thread per constrained row
 __global__ void k_dirichlet(int n, int resid, int eq, int32_t const* nodes, double const* values, double const* x,
                             int32_t const* nodeptr, int32_t const* nodeadj, double* A_i0, double* A_i1, double* b,
-                            int is_adjoint, int nowned, int ndims) {
+                            int is_adjoint, int nowned, int ndims, int nres) {
   int const t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   int const node = nodes[t];
@@ -31,7 +31,7 @@ __global__ void k_dirichlet(int n, int resid, int eq, int32_t const* nodes, doub
   int const row = node * ni + eq;
   int64_t const np = nodeptr[node], deg = nodeptr[node + 1] - np;
   double diag = 0.;
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < nres; ++j) {
     int const nj = neq_of(j, ndims);
     double* vals = (j == 0 ? A_i0 : A_i1) + np * ni * nj + (int64_t)eq * deg * nj;  // start of this CSR row
     for (int64_t k = 0; k < deg; ++k)
@@ -144,11 +144,11 @@ int c8_apply_dirichlet(c8_ctx* c, int n, const c8_dbc* dbcs, const double* const
   if (!c || n < 0 || (n > 0 && !dbcs) || !x || !sys) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: null argument");
   for (int q = 0; q < n; ++q) {  // in deck order: later conditions overwrite earlier ones on shared rows
     c8_dbc const& d = dbcs[q];
-    if (d.resid < 0 || d.resid > 1 || d.eq < 0 || d.eq >= neq_of(d.resid, c->ndims)) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: bad residual/equation index");
+    if (d.resid < 0 || d.resid >= c->nres || d.eq < 0 || d.eq >= neq_of(d.resid, c->ndims)) return c8_fail(C8_ERR_ARG, "c8_apply_dirichlet: bad residual/equation index");
     if (d.n <= 0) continue;
     hipLaunchKernelGGL(k_dirichlet, dim3(grid_of(d.n)), dim3(TPB), 0, c->stream, d.n, d.resid, d.eq, d.nodes, d.values,
                        x[d.resid], c->d_nodeptr, c->d_nodeadj, sys->A[d.resid][0], sys->A[d.resid][1], sys->b[d.resid], is_adjoint,
-                       c->halo ? c8_halo_num_owned(c->halo) : c->mesh.nnodes, c->ndims);
+                       c->halo ? c8_halo_num_owned(c->halo) : c->mesh.nnodes, c->ndims, c->nres);
     C8P_HIP(hipGetLastError());
   }
   return C8_OK;
@@ -193,8 +193,8 @@ int c8_face_points(int npf, int n, const double* coords, const int32_t* faces, d
 
 int c8_apply_A(c8_ctx* c, const c8_system* sys, const double* const x[2], double* const y[2]) {
   if (!c || !sys || !x || !y) return c8_fail(C8_ERR_ARG, "c8_apply_A: null argument");
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j) {
+  for (int i = 0; i < c->nres; ++i)
+    for (int j = 0; j < c->nres; ++j) {
       hipLaunchKernelGGL(k_spmv, dim3(grid_of((size_t)c->mesh.nnodes * neq_of(i, c->ndims))), dim3(TPB), 0, c->stream, c->mesh.nnodes, i, j,
                          c->d_nodeptr, c->d_nodeadj, sys->A[i][j], x[j], y[i], j, c->ndims);
       C8P_HIP(hipGetLastError());
@@ -218,8 +218,10 @@ struct StepSystem {
   size_t nown[2];      // owned rows per block
   size_t nnz[2][2];
   bool parts;
+  int nres;            // blocks in use: 2, or 1 under mechanics_plane_stress
   StepSystem(c8_ctx* ctx, const c8_system* s) : c(ctx), sys(s) {
     parts = ctx->halo != nullptr;
+    nres = ctx->nres;
     int const no = parts ? c8_halo_num_owned(ctx->halo) : ctx->mesh.nnodes;
     for (int i = 0; i < 2; ++i) {
       nloc[i] = (size_t)ctx->mesh.nnodes * neq_of(i, ctx->ndims);
@@ -228,9 +230,9 @@ struct StepSystem {
     }
   }
   int zero() const {  // la->zero_all (linear_alg.cpp:118-129)
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < nres; ++i) {
       C8P_HIP(hipMemsetAsync(sys->b[i], 0, nloc[i] * sizeof(double), c->stream));
-      for (int j = 0; j < 2; ++j) C8P_HIP(hipMemsetAsync(sys->A[i][j], 0, nnz[i][j] * sizeof(double), c->stream));
+      for (int j = 0; j < nres; ++j) C8P_HIP(hipMemsetAsync(sys->A[i][j], 0, nnz[i][j] * sizeof(double), c->stream));
     }
     return C8_OK;
   }
@@ -258,7 +260,7 @@ struct StepSystem {
   int dot_owned(double* const x[2], double* const y[2], double* out) const {
     double s[2] = {0., 0.};
     int rc;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < nres; ++i)
       if ((rc = dot(c, nown[i], x[i], y[i], &s[i])) != C8_OK) return rc;
     double v = s[0] + s[1];
     if (parts && (rc = c8_parts_allreduce(c, &v, 1)) != C8_OK) return rc;
@@ -289,7 +291,7 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
                          const c8_tbc* tbcs, const c8_newton_opts* o, c8_linear_solve_fn solve, void* user, int32_t* iters_out) {
   if (!c || !st || !sys || !o || !solve) return c8_fail(C8_ERR_ARG, "c8_primal_solve_step: null argument");
   StepSystem S(c, sys);
-  if (!c->d_work[0]) {
+  if (!c->d_work[0]) {  // (all four also under mechanics_plane_stress, where the p-sized ones stay unused)
     for (int k = 0; k < 4; ++k) C8P_HIP(hipMalloc((void**)&c->d_work[k], S.nloc[k & 1] * sizeof(double)));
   }
   double* dx[2] = {c->d_work[0], c->d_work[1]};
@@ -322,7 +324,7 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
   // Disc::add_to_soln(x, dx, alpha) (disc.cpp:893-949): dx has been imported to the ghost and phantom copies, so every
   // copy of a node takes the same update and stays equal to its owner's value bit for bit
   auto move = [&](double alpha) {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < S.nres; ++i)
       hipLaunchKernelGGL(k_axpy, dim3(grid_of(S.nloc[i])), dim3(TPB), 0, c->stream, S.nloc[i], alpha, dx[i], x[i]);
   };
 
@@ -337,7 +339,7 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
     if ((rc = residual_norm(&r_abs)) != C8_OK) break;
     if (iter == 1) r_first = r_abs;
     if ((r_abs < o->abs_tol) || (r_abs / r_first < o->rel_tol)) { converged = true; break; }
-    for (int i = 0; i < 2; ++i)  // la->scale_b(-1.)
+    for (int i = 0; i < S.nres; ++i)  // la->scale_b(-1.)
       hipLaunchKernelGGL(k_scale, dim3(grid_of(S.nloc[i])), dim3(TPB), 0, c->stream, S.nloc[i], -1., sys->b[i]);
     C8P_HIP(hipStreamSynchronize(c->stream));
     if (solve(user, sys, dx) != 0) { rc = c8_fail(C8_ERR_ARG, "c8_primal_solve_step: linear solve callback failed"); break; }
@@ -345,11 +347,17 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
     move(1.);
     if (o->line_search) {  // primal.cpp:139-197: merit 1/2 |R|^2, slope at 0 = -|R_0|^2, slope at t = R(t) . (A dx)
       double const f0 = 0.5 * r_abs * r_abs, g0 = -2. * f0;
+      // every trial starts its local solves from the local state of the base point (primal.cpp:146-156), so the merit is
+      // one fixed function of the step and a trial whose local solves diverged leaves nothing behind
+      size_t const xi_bytes = (size_t)c->mesh.nelems * c->npts0 * c->nloc * sizeof(double);
+      if (!c->d_xi_saved) C8P_HIP(hipMalloc((void**)&c->d_xi_saved, xi_bytes));
+      C8P_HIP(hipMemcpyAsync(c->d_xi_saved, st->xi, xi_bytes, hipMemcpyDeviceToDevice, c->stream));
       double t = 1., t_now = 1., t_best = 1., f_best = std::numeric_limits<double>::max();
       bool any_assembled = false, accepted = false;
       for (int trial = 1; trial <= o->max_evals && !accepted; ++trial) {
         move(t - t_now);
         t_now = t;
+        C8P_HIP(hipMemcpyAsync(st->xi, c->d_xi_saved, xi_bytes, hipMemcpyDeviceToDevice, c->stream));
         int const arc = assemble();
         if (arc == C8_LOCAL_SOLVE_FAILED) { t *= 0.5; continue; }  // a local solve diverged: contract and retry
         if (arc != C8_OK) { rc = arc; break; }
@@ -385,7 +393,7 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
 int c8_adjoint_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, int ndbc, const c8_dbc* dbcs,
                           c8_linear_solve_fn solve, void* user, double* const z[2], double* phi, double* g, double* f,
                           double* grad) {
-  if (!c || !st || !sys || !solve || !z || !z[0] || !z[1] || !phi || !g || !f || !grad)
+  if (!c || !st || !sys || !solve || !z || !z[0] || (c->nres == 2 && !z[1]) || !phi || !g || !f || !grad)
     return c8_fail(C8_ERR_ARG, "c8_adjoint_solve_step: null argument");
   StepSystem S(c, sys);
   int rc = S.zero();  // la->zero_all (adjoint.cpp:118)

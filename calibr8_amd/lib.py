@@ -31,7 +31,7 @@ class MeshDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("global_type", C.c_char_p), ("local_type", C.c_char_p), ("stabilization_multiplier", C.c_double),
                 ("local_max_iters", C.c_int32), ("local_abs_tol", C.c_double), ("local_rel_tol", C.c_double),
-                ("num_params", C.c_int32), ("params", dp)]
+                ("num_params", C.c_int32), ("params", dp), ("thickness", C.c_double)]
 
 
 class Dbc(C.Structure):
@@ -99,6 +99,7 @@ SYMBOLS = [
     ("c8_build_info", C.c_char_p, []),
     ("c8_num_local_dofs", C.c_int, [C.c_void_p]),
     ("c8_num_dims", C.c_int, [C.c_void_p]),
+    ("c8_num_residuals", C.c_int, [C.c_void_p]),
     ("c8_num_local_points", C.c_int, [C.c_void_p]),
     ("c8_num_colors", C.c_int, [C.c_void_p]),
     ("c8_graph_nnz", C.c_int64, [C.c_void_p, C.c_int, C.c_int]),

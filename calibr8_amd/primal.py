@@ -22,17 +22,20 @@ def scipy_solver(asm):
     nnz = asm.nnz
     NEQ = asm.neq
 
+    nres = getattr(asm, "nres", 2)  # 1 under mechanics_plane_stress: the system is the u block alone
+
     def solve(user, sys_p, dx_p):
         sys = sys_p.contents
-        blocks = [[None, None], [None, None]]
-        for i in range(2):
-            for j in range(2):
+        blocks = [[None] * nres for _ in range(nres)]
+        for i in range(nres):
+            for j in range(nres):
                 vals = _DevView(sys.A[i][j], nnz[i][j], asm.device).to_numpy()
                 blocks[i][j] = sp.csr_matrix((vals, ci[i][j], rp[i][j]), shape=(n * NEQ[i], n * NEQ[j]))
-        b = np.concatenate([_DevView(sys.b[i], n * NEQ[i], asm.device).to_numpy() for i in range(2)])
+        b = np.concatenate([_DevView(sys.b[i], n * NEQ[i], asm.device).to_numpy() for i in range(nres)])
         x = spla.spsolve(sp.bmat(blocks, format="csc"), b)
         _DevView(dx_p[0], n * NEQ[0], asm.device).from_numpy(x[: n * NEQ[0]])
-        _DevView(dx_p[1], n, asm.device).from_numpy(x[n * NEQ[0]:])
+        if nres == 2:
+            _DevView(dx_p[1], n, asm.device).from_numpy(x[n * NEQ[0]:])
         return 0
 
     return _l.LINEAR_SOLVE_FN(solve)

@@ -68,11 +68,14 @@ typedef struct {
 
 /* The `residuals:` block of a deck (global_residual.cpp:620-630, local_residual.cpp:893-933). */
 typedef struct {
-  const char* global_type;          /* "mechanics" (mixed u-p formulation) */
+  const char* global_type;          /* "mechanics" (mixed u-p formulation, two residuals), or on tri3 meshes
+                                       "mechanics_plane_stress" (mechanics_plane_stress.cpp: ONE residual, u; it pairs
+                                       with the *_plane_stress local residuals and only with them) */
   const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" | "small_hill" | "isotropic_elastic" |
                                        "hypo_hill"; on tri3 meshes "small_J2" | "small_hill_plane_strain" |
-                                       "hyper_J2_plane_strain" | "hypo_hill_plane_strain"
-                                       (the names of local_residual.cpp:893-933) */
+                                       "hyper_J2_plane_strain" | "hypo_hill_plane_strain", and under
+                                       mechanics_plane_stress "small_hill_plane_stress" | "hyper_J2_plane_stress" |
+                                       "hypo_hill_plane_stress" (the names of local_residual.cpp:893-933) */
   double stabilization_multiplier;  /* mechanics.cpp:47 */
   int32_t local_max_iters;          /* "nonlinear max iters" of the local residual */
   double local_abs_tol;             /* "nonlinear absolute tol" */
@@ -80,11 +83,15 @@ typedef struct {
   int32_t num_params;               /* elastic 4 (E nu cte delta_T), small_J2 6 (E nu K Y cte delta_T),
                                        hyper_J2 8 (E nu Y S D A n K), small_hill / hypo_hill 11 (E nu Y R00 R11 R22
                                        R01 R02 R12 S D), isotropic_elastic 2 (E nu), small_hill_plane_strain /
-                                       hypo_hill_plane_strain 9 (E nu Y S D R00 R11 R22 R01), hyper_J2_plane_strain 6 (E nu K Y Y_inf delta) */
+                                       hypo_hill_plane_strain 9 (E nu Y S D R00 R11 R22 R01), hyper_J2_plane_strain 6 (E nu K Y Y_inf delta),
+                                       small_hill_plane_stress 9 (as plane strain), hyper_J2_plane_stress 8 (as hyper_J2),
+                                       hypo_hill_plane_stress 13 (the nine + Q00 Q01 Q10 Q11) */
   const double* params;             /* [num_elem_sets][num_params] */
+  double thickness;                 /* mechanics_plane_stress.cpp:22 "thickness"; 0 = the reference's default 1 */
 } c8_model_desc;
 
-/* Primal state at one load step (DEVICE pointers). */
+/* Primal state at one load step (DEVICE pointers).  Under mechanics_plane_stress (c8_num_residuals() == 1) the entries
+ * [1] of a state, of a system (A[i][j] with i or j = 1, b[1]) and of an adjoint vector z are not read and may be NULL. */
 typedef struct {
   const double* x[2];      /* x[0] = u [num_nodes*3], x[1] = p [num_nodes]  at step n   */
   const double* x_prev[2]; /* same at step n-1                                           */
@@ -112,6 +119,7 @@ const char* c8_build_info(void);
 /* ---- discretisation queries (host arrays) ------------------------------------------------ */
 int c8_num_local_dofs(const c8_ctx* ctx);    /* LocalResidual::num_dofs: 1 / 7 / 8 (3-D), 4 (2-D) */
 int c8_num_dims(const c8_ctx* ctx);          /* 3, or 2 on a tri3 mesh: equations per node of residual 0 */
+int c8_num_residuals(const c8_ctx* ctx);     /* GlobalResidual::num_residuals: 2 (mechanics: u, p) or 1 (mechanics_plane_stress: u) */
 int c8_num_local_points(const c8_ctx* ctx);  /* points of the local-state field per element */
 int c8_num_colors(const c8_ctx* ctx);
 /* Block (i,j) CSR graph = m_graphs[GHOST][i][j] (disc.cpp:356-387): sorted columns. */

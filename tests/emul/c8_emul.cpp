@@ -220,6 +220,10 @@ static int dispatch_2d(std::string const& model, Call const& c) {
   else if (model == "small_hill_plane_strain") run<E, SmallHillPlaneStrain>(c);
   else if (model == "hyper_J2_plane_strain") run<E, HyperJ2PlaneStrain>(c);
   else if (model == "hypo_hill_plane_strain") run<E, HypoHillPlaneStrain>(c);
+  // `mechanics_plane_stress`: one residual, six element DOFs
+  else if (model == "small_hill_plane_stress") run<Tri3PlaneStress, SmallHillPlaneStress>(c);
+  else if (model == "hyper_J2_plane_stress") run<Tri3PlaneStress, HyperJ2PlaneStress>(c);
+  else if (model == "hypo_hill_plane_stress") run<Tri3PlaneStress, HypoHillPlaneStress>(c);
   else return -2;
   return 0;
 }

@@ -21,12 +21,18 @@ CASES = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("elastic", EL, 0.002
 MESHES = ["hex8", "tet4"]
 ACTIVE = {"small_J2": [0, 1, 2, 3], "elastic": [0, 1], "hyper_J2": [0, 1, 2, 3, 4, 7], "small_hill": [0, 2, 3, 6, 9, 10], "isotropic_elastic": [0, 1],
           "hypo_hill": [0, 2, 3, 6, 9, 10], "small_hill_plane_strain": [0, 2, 3, 4, 5, 8], "hyper_J2_plane_strain": [0, 1, 2, 3, 4, 5],
-          "hypo_hill_plane_strain": [0, 2, 3, 4, 5, 8]}
+          "hypo_hill_plane_strain": [0, 2, 3, 4, 5, 8], "small_hill_plane_stress": [0, 2, 3, 4, 5, 8],
+          "hyper_J2_plane_stress": [0, 1, 2, 3, 4, 7], "hypo_hill_plane_stress": [0, 2, 3, 8, 9, 12]}
 # 2-D (tri3) cases: the models of the reference's 2-D decks that run on `mechanics` with 2 + 1 equations per node
 HILL_PS = [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.1, 0.9, 1.05]  # E nu Y S D R00 R11 R22 R01
 HJ2_PS = [1000.0, 0.25, 100.0, 2.0, 3.0, 40.0]  # E nu K Y Y_inf delta
 CASES_2D = [("small_J2", J2, 0.001), ("small_J2", J2, 0.004), ("small_hill_plane_strain", HILL_PS, 0.004),
             ("hyper_J2_plane_strain", HJ2_PS, 0.004), ("hypo_hill_plane_strain", HILL_PS, 0.004)]
+# the models of `mechanics_plane_stress` (ONE global residual: six element DOFs on tri3)
+HJ2_PSS = [1000.0, 0.25, 2.0, 10.0, 2.0, 3.0, 0.6, 40.0]  # E nu Y S D A n K
+HYPO_PSS = HILL_PS + [0.96, -0.28, 0.28, 0.96]              # ... + Q00 Q01 Q10 Q11: material axes rotated by 16 degrees
+CASES_PLANE_STRESS = [("small_hill_plane_stress", HILL_PS, 0.001), ("small_hill_plane_stress", HILL_PS, 0.004),
+                      ("hyper_J2_plane_stress", HJ2_PSS, 0.004), ("hypo_hill_plane_stress", HYPO_PSS, 0.004)]
 
 
 def mesh_2d(kind="structured"):
@@ -69,7 +75,7 @@ def jacobian_at_state(orc, u, p, up, pp, xip, xi):
     import scipy.sparse as sp
     ls = orc.new_linsys()
     orc.adjoint_jacobian(u, p, up, pp, xip, xi, np.zeros((orc.nelems, orc.npts, orc.nloc)),
-                         np.zeros((orc.nelems, orc.npts, (getattr(orc, "ndims", 3) + 1) * orc.nn)), ls)
+                         np.zeros((orc.nelems, orc.npts, orc.ndofs)), ls)
     shape = lambda i, j: (len(orc.rowptr[i][j]) - 1, len(orc.rowptr[j][i]) - 1)
     T = [[sp.csr_matrix((ls.A[j][i], orc.colidx[j][i], orc.rowptr[j][i]), shape=shape(j, i)).T.tocsr() for j in range(2)]
          for i in range(2)]
@@ -134,7 +140,7 @@ def check_adjoint_chain(orc, dut, c, model, eps, tol):
     act = ACTIVE[model]
     orc.set_active(0, act)
     dut.set_active(0, act)
-    nd = (getattr(orc, "ndims", 3) + 1) * orc.nn
+    nd = orc.ndofs
     rng = np.random.default_rng(11)
     g_o = np.zeros((orc.nelems, orc.npts, orc.nloc))
     f_o = np.zeros((orc.nelems, orc.npts, nd))

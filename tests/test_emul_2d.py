@@ -6,7 +6,7 @@ import pytest
 
 import emul_lib as em
 import oracle_lib as ol
-from parity_cases import ACTIVE, CASES_2D, check_adjoint_chain, check_forward, check_residual, mesh_2d
+from parity_cases import ACTIVE, CASES_2D, CASES_PLANE_STRESS, check_adjoint_chain, check_forward, check_residual, mesh_2d
 
 
 @pytest.mark.parametrize("mesh", ["structured", "notch2D"])
@@ -19,6 +19,29 @@ def test_emulated_2d_kernels_match_oracle(model, params, eps, mesh):
     check_forward(orc, dut, c, model, eps, 1e-12)
     check_residual(orc, dut, c, eps, 1e-12)
     check_adjoint_chain(orc, dut, c, model, eps, 1e-12)
+
+
+@pytest.mark.parametrize("mesh", ["structured", "notch2D"])
+@pytest.mark.parametrize("model,params,eps", CASES_PLANE_STRESS)
+def test_emulated_plane_stress_kernels_match_oracle(model, params, eps, mesh):
+    # `mechanics_plane_stress`: one global residual (u), one ip set, six element DOFs; the p arrays and the other three
+    # blocks of the test containers must come back untouched (compare_systems checks them against the oracle's zeros)
+    et, c, conn = mesh_2d(mesh)
+    orc = ol.Oracle(et, c, conn, model, params)
+    dut = em.Emul(et, c, conn, model, params)
+    assert orc.nres == 1 and orc.ndims == 2 and orc.nloc in (4, 5, 6) and orc.ndofs == 6
+    check_forward(orc, dut, c, model, eps, 1e-12)
+    check_residual(orc, dut, c, eps, 1e-12)
+    check_adjoint_chain(orc, dut, c, model, eps, 1e-12)
+
+
+def test_plane_stress_plastic_branch_ran():
+    from parity_cases import two_steps
+    et, c, conn = mesh_2d("structured")
+    for model, params, eps in CASES_PLANE_STRESS[1:]:
+        st = two_steps(ol.Oracle(et, c, conn, model, params), c, eps)
+        alpha = st[2][2][:, :, 3 if model != "hyper_J2_plane_stress" else 5]
+        assert (alpha > 0).mean() > 0.3, model
 
 
 def test_2d_plastic_branch_ran():

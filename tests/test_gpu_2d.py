@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from parity_cases import CASES_2D, check_adjoint_chain, check_forward, check_residual, mesh_2d
+from parity_cases import CASES_2D, CASES_PLANE_STRESS, check_adjoint_chain, check_forward, check_residual, mesh_2d
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +26,61 @@ def test_2d_kernels_match_oracle(model, params, eps, mesh, scatter):
     check_forward(orc, gpu, c, model, eps, 1e-12)
     check_residual(orc, gpu, c, eps, 1e-12)
     check_adjoint_chain(orc, gpu, c, model, eps, 1e-12)
+
+
+@pytest.mark.parametrize("scatter", ["colored", "atomic"])
+@pytest.mark.parametrize("mesh", ["structured", "notch2D"])
+@pytest.mark.parametrize("model,params,eps", CASES_PLANE_STRESS)
+def test_plane_stress_kernels_match_oracle(model, params, eps, mesh, scatter):
+    # `mechanics_plane_stress` (one global residual): Tri3PlaneStress lane groups of six, every entry point at 1e-12;
+    # the p arrays and the three other blocks of the test containers must stay untouched (compared with the oracle's zeros)
+    from gpu_backend import GpuBackend
+    et, c, conn = mesh_2d(mesh)
+    orc = ol.Oracle(et, c, conn, model, params)
+    gpu = GpuBackend(et, c, conn, model, params, scatter=scatter)
+    assert gpu.asm.nres == 1 and gpu.ndims == 2 and gpu.asm.ndofs == 6 and gpu.nloc == orc.nloc
+    check_forward(orc, gpu, c, model, eps, 1e-12)
+    check_residual(orc, gpu, c, eps, 1e-12)
+    check_adjoint_chain(orc, gpu, c, model, eps, 1e-12)
+
+
+def test_plane_stress_abi_ignores_the_second_residual_and_refuses_mismatched_pairs():
+    import ctypes as C
+    import torch
+    from calibr8_amd import Assembler, lib as _l
+    from calibr8_amd.lib import C8Error
+    from parity_cases import HILL_PS, two_steps
+    et, c, conn = mesh_2d("structured")
+    asm = Assembler(3, c, conn, "small_hill_plane_stress", HILL_PS, thickness=0.7)
+    assert asm.nres == 1 and asm.scatter == "colored"
+    with pytest.raises(C8Error):  # the pairing is fixed: plane-stress models under mechanics_plane_stress only ...
+        Assembler(3, c, conn, "small_hill_plane_stress", HILL_PS, global_type="mechanics")
+    with pytest.raises(C8Error):  # ... and only they
+        Assembler(3, c, conn, "small_hill_plane_strain", HILL_PS, global_type="mechanics_plane_stress")
+    with pytest.raises(C8Error):  # six lanes per element group: at most six active parameters
+        asm.set_active(0, [0, 1, 2, 3, 4, 5, 6])
+    # NULL in every [1] entry of state and system; thickness scales A and b
+    orc = ol.Oracle(et, c, conn, "small_hill_plane_stress", HILL_PS)
+    orc.set_thickness(0.7)
+    (u, p, xi), (up, pp, xip) = two_steps(orc, c, 0.004)[1], two_steps(orc, c, 0.004)[0]
+    ls_o, xo = orc.new_linsys(), orc.new_state()
+    assert orc.forward_jacobian(u, p, up, pp, xip, xo, ls_o) == 0
+    d = lambda a: asm.dev(a)
+    du, dup, dxip, dxi = d(u), d(up), d(xip), asm.new_state()
+    A00 = torch.zeros(asm.nnz[0][0], dtype=torch.float64, device=asm.device)
+    b0 = torch.zeros(asm.nnodes * 2, dtype=torch.float64, device=asm.device)
+    st, sy = _l.State(), _l.System()
+    st.x[0], st.x_prev[0], st.xi_prev, st.xi = du.data_ptr(), dup.data_ptr(), dxip.data_ptr(), dxi.data_ptr()
+    sy.A[0][0], sy.b[0] = A00.data_ptr(), b0.data_ptr()
+    assert asm.L.c8_assemble_forward_jacobian(asm.h, C.byref(st), C.byref(sy)) == 0
+    torch.cuda.synchronize()
+    from parity import rel_csr_rows, rel_vec
+    assert rel_vec(b0.cpu().numpy(), ls_o.b[0]) < 1e-12
+    assert rel_csr_rows(A00.cpu().numpy(), ls_o.A[0][0], orc.rowptr[0][0]) < 1e-12
+    # a Dirichlet condition on residual 1 does not exist here
+    with pytest.raises(C8Error):
+        nodes = torch.zeros(1, dtype=torch.int32, device=asm.device)
+        asm.apply_dirichlet([(1, 0, nodes, d(np.zeros(1)))], du, du, asm.new_linsys())
 
 
 def test_2d_default_mode_and_refusals():
@@ -79,6 +134,61 @@ def test_notch2D_regressions_with_device_newton_driver(deck):
     assert drv.newton_iters == pr.newton_iters, (drv.newton_iters, pr.newton_iters)
     assert abs(J - pr.qoi()) < 1e-10 * abs(J)
     assert float(drv.xi[-1][:, :, -1].max()) > 1e-3
+
+
+@pytest.mark.parametrize("deck", ["notch2D_small_J2_plane_stress", "notch2D_hyper_J2_plane_stress", "notch2D_hypo_J2_plane_stress"])
+def test_notch2D_plane_stress_regressions_with_device_newton_driver(deck):
+    # the reference's three `mechanics_plane_stress` decks end to end on the device: one-residual system, the C++ Newton
+    # driver with the line search that restores the local state before each trial (primal.cpp:146-156; the
+    # hyper_J2_plane_stress deck needs it: its local solves fail at the full step of the second Newton iteration)
+    from calibr8_amd import Assembler
+    from calibr8_amd.primal import PrimalDriver
+    c, conn, ns = notch2d()
+    if deck == "notch2D_small_J2_plane_stress":
+        model, params, rate, nsteps, pin, tol = "small_hill_plane_stress", [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0], 0.001, 4, 2.2831790025047405e-03, 1e-9
+    elif deck == "notch2D_hyper_J2_plane_stress":
+        model, params, rate, nsteps, pin, tol = "hyper_J2_plane_stress", [1000.0, 0.25, 2.0, 10.0, 2.0, 0.0, 0.0, 0.0], 0.005, 5, 1.7493199283412385e-02, 1e-8
+    else:
+        model, params, rate, nsteps, pin, tol = "hypo_hill_plane_stress", [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0], 0.005, 4, 1.1852379652063684e-02, 1e-8
+    asm = Assembler(3, c, conn, model, params)
+    dbcs = [(0, 0, ns["xmin"], lambda x, y, z, t: 0.0), (0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            (0, 1, ns["ymax"], lambda x, y, z, t: rate * t)]
+    drv = PrimalDriver(asm, dbcs, max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(nsteps)
+    J = drv.qoi()
+    assert abs(J - pin) / pin < tol, (deck, J, pin)
+    from fe_driver import Dbc, Primal
+    orc = ol.Oracle(ol.TRI3, c, conn, model, params)
+    pr = Primal(orc, c, [Dbc(r, e, n, f) for r, e, n, f in dbcs], max_iters=30, abs_tol=1e-8, rel_tol=1e-8).solve(nsteps)
+    assert drv.newton_iters == pr.newton_iters, (drv.newton_iters, pr.newton_iters)
+    assert abs(J - pr.qoi()) < 1e-10 * abs(J)
+    assert not bool(drv.p[-1].any())
+
+
+def test_plane_stress_adjoint_gradient_on_device_passes_fd_check():
+    # the adjoint chain of a one-residual system (K3 -> solve -> K4 -> K5 through c8_adjoint_solve_step) against central
+    # differences of the device objective
+    from calibr8_amd import Assembler
+    from calibr8_amd.primal import PrimalDriver, adjoint_gradient
+    c, conn, ns = notch2d()
+    dbcs = [(0, 0, ns["xmin"], lambda x, y, z, t: 0.0), (0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            (0, 1, ns["ymax"], lambda x, y, z, t: 0.001 * t)]
+    p0 = np.array([1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0])
+    act = [0, 1, 2, 3]
+    span = np.array([100.0, 0.05, 1.0, 2.0])
+
+    def solve(p):
+        asm = Assembler(3, c, conn, "small_hill_plane_stress", list(p))
+        asm.set_active(0, act)
+        return PrimalDriver(asm, dbcs, max_iters=30, abs_tol=1e-12, rel_tol=1e-12).solve(3)
+
+    gd = float(adjoint_gradient(solve(p0), 4) * span @ np.full(4, 0.1))
+    errs = []
+    for h in (1e-2, 1e-3, 1e-4):
+        pp, pm = p0.copy(), p0.copy()
+        pp[act] += h * 0.1 * span
+        pm[act] -= h * 0.1 * span
+        errs.append(abs((solve(pp).qoi() - solve(pm).qoi()) / (2 * h) - gd))
+    assert min(errs) < 1e-6 * abs(gd), (errs, gd)
 
 
 def test_notch2D_adjoint_gradient_on_device_passes_fd_check():
