@@ -33,6 +33,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -168,6 +169,23 @@ inline Fad exp(Fad const& a) {
   for (int i = 0; i < a.n; ++i) r.d[i] = r.v * a.d[i];
   return r;
 }
+inline Fad log(Fad const& a) {
+  Fad r; r.v = std::log(a.v); r.n = a.n;
+  for (int i = 0; i < a.n; ++i) r.d[i] = a.d[i] / a.v;
+  return r;
+}
+inline Fad cos(Fad const& a) {
+  Fad r; r.v = std::cos(a.v); r.n = a.n;
+  double const s = -std::sin(a.v);
+  for (int i = 0; i < a.n; ++i) r.d[i] = s * a.d[i];
+  return r;
+}
+inline Fad acos(Fad const& a) {
+  Fad r; r.v = std::acos(a.v); r.n = a.n;
+  double const s = -1. / std::sqrt(1. - a.v * a.v);
+  for (int i = 0; i < a.n; ++i) r.d[i] = s * a.d[i];
+  return r;
+}
 inline Fad abs(Fad const& a) {
   Fad r; r.v = std::fabs(a.v); r.n = a.n;
   double const s = a.v >= 0. ? 1. : -1.;
@@ -185,6 +203,9 @@ inline Fad pow(Fad const& a, Fad const& b) {  // Sacado's PowerOp: which formula
   return r;
 }
 using std::abs;
+using std::acos;
+using std::cos;
+using std::log;
 using std::cbrt;
 using std::exp;
 using std::pow;
@@ -301,6 +322,137 @@ template <class T> T norm(Tens<T> const& A) {
   T s = A(0, 0) * A(0, 0);
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (i || j) s += A(i, j) * A(i, j);
   return sqrt(s);
+}
+
+// ---------------------------------------------------------------------------
+// minitensor::eig_spd_cos (Trilinos MiniTensor, MiniTensor_LinearAlgebra.t.h; third party, not in /root/reference --
+// the reference pins Trilinos through its build): closed-form eigen-decomposition of a symmetric
+// 3 x 3 tensor (Scherzinger & Dohrmann, CMAME 197 (2008) 4007-4015), restated from the published algorithm: the most
+// distinct eigenvalue from the trigonometric solution of the characteristic equation of the deviator, its eigenvector
+// from the column space of (A' - lambda I) by Gram-Schmidt with column pivoting, the other two from the 2 x 2 problem on
+// the orthogonal complement.  Everything is templated on the scalar, so derivatives flow through it as in the
+// reference.  An (almost) diagonal input returns V = I, D = A at once.  Returned: eigenvectors in the COLUMNS of V.
+// The yield functions that call it are symmetric in the eigenpairs, so neither their order nor the signs of the
+// vectors matter to the callers.
+// ---------------------------------------------------------------------------
+template <class T> void eig_spd_cos(Tens<T> const& A, Tens<T>& V, Tens<T>& D) {
+  V = Tens<T>();
+  D = Tens<T>();
+  double off = 0.;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (i != j) off += val(A(i, j)) * val(A(i, j));
+  if (std::sqrt(off) <= std::numeric_limits<double>::epsilon()) {
+    V = eye<T>();
+    D = A;
+    return;
+  }
+  double const pi = std::acos(-1.);
+  int const ii[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+  T const trA = (1. / 3.) * trace(A);
+  Tens<T> const Ap = A - trA * eye<T>();
+  T const J2 = -(Ap(0, 0) * Ap(1, 1) + Ap(1, 1) * Ap(2, 2) + Ap(2, 2) * Ap(0, 0)) + Ap(0, 1) * Ap(0, 1) + Ap(1, 2) * Ap(1, 2) +
+               Ap(2, 0) * Ap(2, 0);  // second invariant of the deviator, = 1/2 Ap : Ap >= 0
+  T const J3 = det(Ap);
+  if (val(J2) <= 1.e-30) {  // volumetric tensor
+    D(0, 0) = trA; D(1, 1) = trA; D(2, 2) = trA;
+    V = eye<T>();
+    return;
+  }
+  // cos(3 theta) = J3/2 (3/J2)^(3/2): the eigenvalue with the largest distance from the other two
+  T const t1 = 3. / J2;
+  T const rhs = (J3 / 2.) * sqrt(t1 * t1 * t1);
+  T theta = T(pi / 2. * (1. - (val(rhs) < 0. ? -1. : 1.)));
+  if (std::fabs(val(rhs)) <= 1.) theta = acos(rhs);
+  T thetad3 = theta / 3.;
+  if (val(thetad3) > pi / 6.) thetad3 = thetad3 + 2. * pi / 3.;
+  D(2, 2) = 2. * cos(thetad3) * sqrt(J2 / 3.);
+  Tens<T> R = Ap - D(2, 2) * eye<T>();
+  // Gram-Schmidt with column pivoting on R: its two-dimensional column space is orthogonal to the eigenvector
+  T a[3];
+  for (int j = 0; j < 3; ++j) a[j] = R(0, j) * R(0, j) + R(1, j) * R(1, j) + R(2, j) * R(2, j);
+  int k = 0;
+  if (val(a[1]) > val(a[k])) k = 1;
+  if (val(a[2]) > val(a[k])) k = 2;
+  T const nk = sqrt(a[k]);
+  for (int i = 0; i < 3; ++i) R(i, k) = R(i, k) / nk;
+  T d0 = 0., d1 = 0.;
+  for (int i = 0; i < 3; ++i) { d0 += R(i, k) * R(i, ii[k][0]); d1 += R(i, k) * R(i, ii[k][1]); }
+  for (int i = 0; i < 3; ++i) { R(i, ii[k][0]) = R(i, ii[k][0]) - d0 * R(i, k); R(i, ii[k][1]) = R(i, ii[k][1]) - d1 * R(i, k); }
+  T b0 = 0., b1 = 0.;
+  for (int i = 0; i < 3; ++i) { b0 += R(i, ii[k][0]) * R(i, ii[k][0]); b1 += R(i, ii[k][1]) * R(i, ii[k][1]); }
+  int const p = (std::fabs(val(b1)) > std::fabs(val(b0))) ? 1 : 0;
+  int const k2 = ii[k][p];
+  T const nk2 = sqrt(p ? b1 : b0);
+  for (int i = 0; i < 3; ++i) R(i, k2) = R(i, k2) / nk2;
+  // eigenvector of D(2,2): s1 x s2
+  V(0, 2) = R(1, k) * R(2, k2) - R(2, k) * R(1, k2);
+  V(1, 2) = R(2, k) * R(0, k2) - R(0, k) * R(2, k2);
+  V(2, 2) = R(0, k) * R(1, k2) - R(1, k) * R(0, k2);
+  T mag = sqrt(V(0, 2) * V(0, 2) + V(1, 2) * V(1, 2) + V(2, 2) * V(2, 2));
+  for (int i = 0; i < 3; ++i) V(i, 2) = V(i, 2) / mag;
+  // the 2 x 2 problem on span{s1, s2}
+  T rk[3], rk2[3], ak[3], ak2[3];
+  for (int i = 0; i < 3; ++i) { rk[i] = R(i, k); rk2[i] = R(i, k2); }
+  for (int i = 0; i < 3; ++i) {
+    ak[i] = Ap(i, 0) * rk[0] + Ap(i, 1) * rk[1] + Ap(i, 2) * rk[2];
+    ak2[i] = Ap(i, 0) * rk2[0] + Ap(i, 1) * rk2[1] + Ap(i, 2) * rk2[2];
+  }
+  T rm00 = rk[0] * ak[0] + rk[1] * ak[1] + rk[2] * ak[2];
+  T const rm01 = rk[0] * ak2[0] + rk[1] * ak2[1] + rk[2] * ak2[2];
+  T rm11 = rk2[0] * ak2[0] + rk2[1] * ak2[1] + rk2[2] * ak2[2];
+  T const b = 0.5 * (rm00 - rm11);
+  double const fac = val(b) < 0. ? -1. : 1.;
+  T const arg = b * b + rm01 * rm01;
+  if (val(arg) == 0.) D(0, 0) = rm11 + b;
+  else D(0, 0) = rm11 + b - fac * sqrt(arg);
+  D(1, 1) = rm00 + rm11 - D(0, 0);
+  rm00 = rm00 - D(0, 0);
+  rm11 = rm11 - D(0, 0);
+  T const c0 = rm00 * rm00 + rm01 * rm01, c1 = rm01 * rm01 + rm11 * rm11;
+  int const k3 = (val(c1) > val(c0)) ? 1 : 0;
+  T m0 = k3 ? rm01 : rm00, m1 = k3 ? rm11 : rm01;  // column k3 of the shifted 2 x 2 matrix
+  if (val(k3 ? c1 : c0) == 0.) { m0 = 1.; m1 = 0.; }
+  // eigenvector of D(0,0): orthogonal to that column within the plane
+  for (int i = 0; i < 3; ++i) V(i, 0) = m0 * rk2[i] - m1 * rk[i];
+  mag = sqrt(V(0, 0) * V(0, 0) + V(1, 0) * V(1, 0) + V(2, 0) * V(2, 0));
+  for (int i = 0; i < 3; ++i) V(i, 0) = V(i, 0) / mag;
+  // the last one completes the triad
+  V(0, 1) = V(1, 0) * V(2, 2) - V(2, 0) * V(1, 2);
+  V(1, 1) = V(2, 0) * V(0, 2) - V(0, 0) * V(2, 2);
+  V(2, 1) = V(0, 0) * V(1, 2) - V(1, 0) * V(0, 2);
+  mag = sqrt(V(0, 1) * V(0, 1) + V(1, 1) * V(1, 1) + V(2, 1) * V(2, 1));
+  for (int i = 0; i < 3; ++i) V(i, 1) = V(i, 1) / mag;
+  for (int i = 0; i < 3; ++i) D(i, i) = D(i, i) + trA;
+}
+template <class T> Tens<T> dyad_col(Tens<T> const& V, int c) {  // dyad(col(V, c), col(V, c))
+  Tens<T> t;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t(i, j) = V(i, c) * V(j, c);
+  return t;
+}
+
+// line_search.hpp:56-135: backtracking Armijo search with two-point cubic interpolation (shared by the global Newton
+// loop, restated for it in tests/fe_driver.py, and the local solves of the Hosford / Barlat models)
+struct LineSearchParams { double c1 = 1.e-4, backtrack_min = 0.5, backtrack_max = 0.9; int max_evals = 4; };
+static double ls_cubic_min(double phi_0, double dphi_0, double a, double phi, double slope_a) {
+  double const d1 = dphi_0 + slope_a - 3. * (phi_0 - phi) / (0. - a);
+  double const radicand = d1 * d1 - dphi_0 * slope_a;
+  if (radicand < 0.) return 0.5 * a;
+  double const d2 = std::sqrt(radicand);
+  double const denom = slope_a - dphi_0 + 2. * d2;
+  if (denom == 0.) return 0.5 * a;
+  return a - a * (slope_a + d2 - d1) / denom;
+}
+template <class Eval> static double line_search(LineSearchParams const& p, double phi_0, double dphi_0, Eval&& eval) {
+  double const armijo_slope = p.c1 * dphi_0;
+  double alpha = 1., best_alpha = 1., best_phi = std::numeric_limits<double>::max();
+  for (int n = 1; n <= p.max_evals; ++n) {
+    double phi, slope;
+    if (!eval(alpha, phi, slope)) { alpha *= 0.5; continue; }
+    if (phi < best_phi) { best_phi = phi; best_alpha = alpha; }
+    if (phi <= phi_0 + alpha * armijo_slope) return alpha;
+    double const alpha_model = ls_cubic_min(phi_0, dphi_0, alpha, phi, slope);
+    alpha = std::min(std::max(alpha_model, p.backtrack_min * alpha), p.backtrack_max * alpha);
+  }
+  return best_alpha;
 }
 
 // ---------------------------------------------------------------------------
@@ -728,6 +880,11 @@ template <class T> struct Local {
 
   // The Newton iteration shared by small_J2.cpp:137-171 and hyper_J2.cpp:181-216
   int newton(Global<T>& g);
+  // The Newton iteration of the Hosford / Barlat models (small_hosford.cpp:147-218, hypo_hosford.cpp:183-254,
+  // hypo_barlat.cpp:353-432): the branch is chosen by the first evaluation and forced afterwards, and every step is
+  // followed by the line search of line_search.hpp on the merit 1/2 |C|^2
+  LineSearchParams ls;
+  int newton_ls(Global<T>& g);
 };
 
 template <> int Local<double>::seed_wrt_xi() { return -1; }
@@ -746,6 +903,7 @@ template <> void Local<double>::set_sym_tensor_xi_val(int i, Tens<double> const&
 }
 template <> void Local<double>::add_to_xi(double const* dxi) { for (int k = 0; k < ndofs; ++k) xi[k] += dxi[k]; }
 template <> int Local<double>::newton(Global<double>&) { return 0; }
+template <> int Local<double>::newton_ls(Global<double>&) { return 0; }
 
 template <> int Local<Fad>::seed_wrt_xi() {
   for (int k = 0; k < ndofs; ++k) xi[k].diff(k, ndofs);
@@ -806,6 +964,58 @@ template <> int Local<Fad>::newton(Global<Fad>& g) {
     for (int k = 0; k < ndofs; ++k) r[k] = -r[k];
     full_piv_lu_solve(ndofs, 1, J, r, dxi);
     this->add_to_xi(dxi);
+    iter++;
+  }
+  if ((iter > max_iters) && (!converged)) return -1;
+  return path;
+}
+
+template <> int Local<Fad>::newton_ls(Global<Fad>& g) {
+  int path = ELASTIC_PATH;
+  int iter = 1;
+  double C_norm_0 = 1.;
+  bool converged = false;
+  while ((iter <= max_iters) && (!converged)) {
+    if (iter == 1) path = this->evaluate(g);
+    else this->evaluate(g, true, path);
+    double const C_norm = this->norm_residual();
+    if (iter == 1) C_norm_0 = C_norm;
+    double const C_norm_rel = C_norm / C_norm_0;
+    if ((C_norm_rel < rel_tol) || (C_norm < abs_tol)) { converged = true; break; }
+    double J[64], r[8], dxi[8], step[8];
+    this->jacobian(ndofs, J);
+    this->residual_values(r);
+    for (int k = 0; k < ndofs; ++k) r[k] = -r[k];
+    full_piv_lu_solve(ndofs, 1, J, r, dxi);
+    this->add_to_xi(dxi);
+    {
+      double const psi_0 = 0.5 * C_norm * C_norm;
+      double const dpsi_0 = -2. * psi_0;
+      double alpha_applied = 1.;  // the full Newton step was applied above
+      auto move = [&](double alpha) {
+        double const alpha_diff = alpha - alpha_applied;
+        alpha_applied = alpha;
+        for (int k = 0; k < ndofs; ++k) step[k] = alpha_diff * dxi[k];
+        this->add_to_xi(step);
+      };
+      auto eval = [&](double alpha, double& phi, double& slope) -> bool {
+        move(alpha);
+        path = this->evaluate(g, true, path);
+        double const C_alpha = this->norm_residual();
+        phi = 0.5 * C_alpha * C_alpha;
+        double Ja[64], Ca[8];
+        this->jacobian(ndofs, Ja);
+        this->residual_values(Ca);
+        slope = 0.;  // phi'(alpha) = C . (J dxi)
+        for (int i = 0; i < ndofs; ++i) {
+          double Jd = 0.;
+          for (int k = 0; k < ndofs; ++k) Jd += Ja[i * ndofs + k] * dxi[k];
+          slope += Ca[i] * Jd;
+        }
+        return true;
+      };
+      move(line_search(ls, psi_0, dpsi_0, eval));
+    }
     iter++;
   }
   if ((iter > max_iters) && (!converged)) return -1;
@@ -1884,6 +2094,237 @@ template <class T> struct HypoHillPlaneStress : Local<T> {
   T pressure_scale_factor() override { return 0.; }
 };
 
+
+// ---------------------------------------------------------------------------
+// Hosford's isotropic yield function on the principal stresses (small_hosford.cpp:228-265, hypo_hosford.cpp:264-301):
+// phi = vm (1/2 sum |(s_i - s_j)/vm|^a)^(1/a), scaled by the von Mises stress so that the powers stay bounded, and its
+// normal through the eigen-dyads.
+// ---------------------------------------------------------------------------
+template <class T> static void hosford_phi_and_normal(Tens<T> const& sigma, T const& vm_stress, T const& a, T& phi, Tens<T>& n) {
+  Tens<T> V, D;
+  eig_spd_cos(sigma, V, D);
+  T const e0 = D(0, 0) / vm_stress, e1 = D(1, 1) / vm_stress, e2 = D(2, 2) / vm_stress;
+  phi = vm_stress * pow(0.5 * (pow(abs(e0 - e1), a) + pow(abs(e1 - e2), a) + pow(abs(e2 - e0), a)), 1. / a);
+  T const q0 = D(0, 0) / phi, q1 = D(1, 1) / phi, q2 = D(2, 2) / phi;
+  T const d01 = q0 - q1, d12 = q1 - q2, d20 = q2 - q0;
+  T const f01 = d01 * pow(abs(d01), a - 2.), f12 = d12 * pow(abs(d12), a - 2.), f20 = d20 * pow(abs(d20), a - 2.);
+  n = 0.5 * ((f01 - f20) * dyad_col(V, 0) + (f12 - f01) * dyad_col(V, 1) + (f20 - f12) * dyad_col(V, 2));
+}
+
+// small_hosford.cpp (pstrain SYM_TENSOR, alpha SCALAR; params E nu Y a K S D)
+template <class T> struct SmallHosford : Local<T> {
+  SmallHosford() { this->nres = 2; this->neq[0] = 6; this->neq[1] = 1; this->finish_layout(); }
+  int num_params() const override { return 7; }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 7; ++k) xi_pt[k] = 0.; }  // :117-129
+  bool is_finite_deformation() const override { return false; }
+  int solve_nonlinear(Global<T>& g) override {  // :136-224
+    if (std::is_same<T, double>::value) return 0;
+    this->set_sym_tensor_xi_val(0, this->sym_tensor_xi_prev(0));
+    this->set_scalar_xi_val(1, val(this->scalar_xi_prev(1)));
+    return this->newton_ls(g);
+  }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :268-340
+    int path = ELASTIC_PATH;
+    T const E = this->params[0], nu = this->params[1], Y = this->params[2], a = this->params[3], K = this->params[4];
+    T const S = this->params[5], D = this->params[6];
+    T const mu = compute_mu(E, nu);
+    Tens<T> const pstrain_old = this->sym_tensor_xi_prev(0);
+    T const alpha_old = this->scalar_xi_prev(1);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    T phi = 0.;
+    Tens<T> n;
+    T const vm_stress = std::sqrt(3. / 2.) * norm(this->dev_cauchy(g));
+    hosford_phi_and_normal(this->cauchy(g), vm_stress, a, phi, n);
+    T const flow_stress = Y + K * alpha + S * (1. - exp(-(D * alpha)));
+    T const f = (phi - flow_stress) / (2. * val(mu));
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    Tens<T> R_pstrain;
+    T R_alpha;
+    if (plastic) {
+      T const dgam = alpha - alpha_old;
+      R_pstrain = pstrain - pstrain_old - dgam * n;
+      R_alpha = f;
+    } else {
+      R_pstrain = pstrain - pstrain_old;
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_pstrain);
+    this->set_scalar_R(1, R_alpha);
+    return path;
+  }
+  Tens<T> cauchy(Global<T>& g) override { return this->dev_cauchy(g) - g.scalar_x(1) * eye<T>(); }  // :343-353
+  Tens<T> dev_cauchy(Global<T>& g) override {  // :356-368
+    T const mu = compute_mu(this->params[0], this->params[1]);
+    Tens<T> const pstrain = this->sym_tensor_xi(0);
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    Tens<T> const dev_eps = eps - (trace(eps) / 3.) * eye<T>();
+    return (2. * mu) * (dev_eps - pstrain);
+  }
+  T hydro_cauchy(Global<T>& g) override {  // :371-378
+    Tens<T> const grad_u = g.grad_vector_x(0);
+    Tens<T> const eps = 0.5 * (grad_u + transpose(grad_u));
+    return compute_kappa(this->params[0], this->params[1]) * trace(eps);
+  }
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
+// the hypoelastic base of hypo_hosford.cpp / hypo_barlat.cpp: unrotated Cauchy stress TC and alpha, the stress measures
+// of hypo_hill.cpp, the elastic predictor as the initial guess
+template <class T> struct HypoBase : Local<T> {
+  HypoBase() { this->nres = 2; this->neq[0] = 6; this->neq[1] = 1; this->finish_layout(); }
+  void init_variables(double* xi_pt) const override { for (int k = 0; k < 7; ++k) xi_pt[k] = 0.; }
+  bool is_finite_deformation() const override { return true; }
+  Tens<T> eval_d(Global<T>& g) {  // hypo_kinematics.hpp:11-18 (the material axes Q of hypo_barlat.cpp default to I)
+    Tens<T> const I = eye<T>();
+    Tens<T> const F = g.grad_vector_x(0) + I;
+    Tens<T> const F_prev = g.grad_vector_x_prev(0) + I;
+    Tens<T> const R = polar_rotation(F);
+    Tens<T> const L = (F - F_prev) * inverse(F);
+    Tens<T> const D = 0.5 * (L + transpose(L));
+    return transpose(R) * D * R;
+  }
+  int solve_nonlinear(Global<T>& g) override {  // hypo_hosford.cpp:160-260, hypo_barlat.cpp:327-438
+    if (std::is_same<T, double>::value) return 0;
+    {
+      double const E = val(this->params[0]), nu = val(this->params[1]);
+      double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+      Tens<T> const d = eval_d(g);
+      Tens<T> const TC = this->sym_tensor_xi_prev(0) + (lambda * trace(d)) * eye<T>() + (2. * mu) * d;
+      this->set_sym_tensor_xi_val(0, TC);
+      this->set_scalar_xi_val(1, val(this->scalar_xi_prev(1)));
+    }
+    return this->newton_ls(g);
+  }
+  // the residual shared by both models once phi (and, on the plastic branch, the normal) is known
+  template <class Normal>
+  int finish(Global<T>& g, T const& phi, T const& flow_stress, Normal&& normal, bool force_path, int path_in) {
+    int path;
+    T const lambda = compute_lambda(this->params[0], this->params[1]), mu = compute_mu(this->params[0], this->params[1]);
+    T const alpha_old = this->scalar_xi_prev(1), alpha = this->scalar_xi(1);
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    T const scale_factor = 2. * mu;
+    T const f = (phi - flow_stress) / scale_factor;
+    Tens<T> const d = eval_d(g);
+    Tens<T> R_TC = (TC - this->sym_tensor_xi_prev(0) - (lambda * trace(d)) * eye<T>() - (2. * mu) * d) / scale_factor;
+    T R_alpha;
+    bool plastic;
+    if (!force_path) {
+      plastic = (f > this->abs_tol || abs(val(f)) < this->abs_tol);
+      path = plastic ? PLASTIC_PATH : ELASTIC_PATH;
+    } else {
+      path = path_in;
+      plastic = (path == PLASTIC_PATH);
+    }
+    if (plastic) {
+      T const dgam = alpha - alpha_old;
+      R_TC = R_TC + dgam * normal();  // the scale factor of R_TC removes the 2 mu multiplier
+      R_alpha = f;
+    } else {
+      R_alpha = alpha - alpha_old;
+    }
+    this->set_sym_tensor_R(0, R_TC);
+    this->set_scalar_R(1, R_alpha);
+    return path;
+  }
+  Tens<T> rotated_cauchy(Global<T>& g) {
+    Tens<T> const R = polar_rotation(g.grad_vector_x(0) + eye<T>());
+    return R * this->sym_tensor_xi(0) * transpose(R);
+  }
+  Tens<T> cauchy(Global<T>& g) override { return this->dev_cauchy(g) - g.scalar_x(1) * eye<T>(); }
+  Tens<T> dev_cauchy(Global<T>& g) override { return dev(rotated_cauchy(g)); }
+  T hydro_cauchy(Global<T>& g) override { return trace(rotated_cauchy(g)) / 3.; }
+  T pressure_scale_factor() override { return compute_kappa(this->params[0], this->params[1]); }
+};
+
+// hypo_hosford.cpp (params E nu Y a K S D; the flow stress has no K term, :326)
+template <class T> struct HypoHosford : HypoBase<T> {
+  int num_params() const override { return 7; }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :304-378
+    T const Y = this->params[2], a = this->params[3], S = this->params[5], D = this->params[6];
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    T phi = 0.;
+    Tens<T> n;
+    T const vm_stress = std::sqrt(3. / 2.) * norm(dev(TC));
+    hosford_phi_and_normal(TC, vm_stress, a, phi, n);
+    T const flow_stress = Y + S * (1. - exp(-(D * this->scalar_xi(1))));
+    return this->finish(g, phi, flow_stress, [&]() { return n; }, force_path, path_in);
+  }
+};
+
+// hypo_barlat.cpp: Barlat's Yld2004-18p on two linear transformations of the stress (yield_functions.hpp:101-386);
+// params E nu Y a K S D sp_01 .. sp_55 dp_01 .. dp_55
+template <class T> struct HypoBarlat : HypoBase<T> {
+  int num_params() const override { return 25; }
+  static void transform(T const* q, Tens<T> const& sigma, T L[6][6], Tens<T>& s) {  // unflatten_barlat_params :162-189, L * stress
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) L[i][j] = 0.;
+    L[0][0] = (q[0] + q[1]) / 3.;       L[0][1] = (-2. * q[0] + q[1]) / 3.; L[0][2] = (q[0] - 2. * q[1]) / 3.;
+    L[1][0] = (-2. * q[2] + q[3]) / 3.; L[1][1] = (q[2] + q[3]) / 3.;       L[1][2] = (q[2] - 2. * q[3]) / 3.;
+    L[2][0] = (-2. * q[4] + q[5]) / 3.; L[2][1] = (q[4] - 2. * q[5]) / 3.;  L[2][2] = (q[4] + q[5]) / 3.;
+    L[3][3] = q[6]; L[4][4] = q[7]; L[5][5] = q[8];
+    T v[6] = {sigma(0, 0), sigma(1, 1), sigma(2, 2), sigma(0, 1), sigma(1, 2), sigma(2, 0)}, w[6];  // flatten_stress :128-141
+    for (int i = 0; i < 6; ++i) { w[i] = L[i][0] * v[0]; for (int j = 1; j < 6; ++j) w[i] += L[i][j] * v[j]; }
+    s(0, 0) = w[0]; s(1, 1) = w[1]; s(2, 2) = w[2];
+    s(0, 1) = s(1, 0) = w[3]; s(1, 2) = s(2, 1) = w[4]; s(0, 2) = s(2, 0) = w[5];
+  }
+  static void flatten(Tens<T> const& t, T* v) { v[0] = t(0, 0); v[1] = t(1, 1); v[2] = t(2, 2); v[3] = t(0, 1); v[4] = t(1, 2); v[5] = t(2, 0); }
+  int evaluate(Global<T>& g, bool force_path, int path_in) override {  // :446-555
+    T const Y = this->params[2], a = this->params[3], K = this->params[4], S = this->params[5], D = this->params[6];
+    T const* sp = &this->params[7];
+    T const* dp = &this->params[16];
+    Tens<T> const TC = this->sym_tensor_xi(0);
+    T const alpha = this->scalar_xi(1);
+    // evaluate_barlat_phi (yield_functions.hpp:322-366)
+    double const vm_phi = std::sqrt(3. / 2.) * val(norm(dev(TC)));
+    T Ls[6][6], Ld[6][6];
+    Tens<T> ss, sd, Vs, Ds, Vd, Dd;
+    transform(sp, TC, Ls, ss);
+    transform(dp, TC, Ld, sd);
+    eig_spd_cos(ss, Vs, Ds);
+    eig_spd_cos(sd, Vd, Dd);
+    T sum = 0.;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) sum += pow(abs(Ds(i, i) / vm_phi - Dd(j, j) / vm_phi), a);
+    sum = 0.25 * sum;
+    T const phi = vm_phi * exp((1.0 / a) * log(sum));
+    T const flow_stress = Y + K * alpha + S * (1. - exp(-(D * alpha)));
+    auto normal = [&]() {  // evaluate_barlat_normal / compute_barlat_normal (:293-320, :369-384)
+      Tens<T> sp_normal, dp_normal;
+      for (int k = 0; k < 3; ++k) {
+        T ms = 0., md = 0.;
+        for (int j = 0; j < 3; ++j) {
+          T const ds = Ds(k, k) / phi - Dd(j, j) / phi;  // sp multiplier (:230-246)
+          ms += ds * pow(abs(ds), a - 2.);
+          T const dd = Ds(j, j) / phi - Dd(k, k) / phi;  // dp multiplier (:258-274)
+          md += -dd * pow(abs(dd), a - 2.);
+        }
+        sp_normal = sp_normal + (0.25 * ms) * dyad_col(Vs, k);
+        dp_normal = dp_normal + (0.25 * md) * dyad_col(Vd, k);
+      }
+      T vs[6], vd[6], w[6];
+      flatten(sp_normal, vs);
+      flatten(dp_normal, vd);
+      for (int i = 0; i < 6; ++i) {
+        w[i] = 0.;
+        for (int j = 0; j < 6; ++j) w[i] += Ls[i][j] * vs[j];
+        for (int j = 0; j < 6; ++j) w[i] += Ld[i][j] * vd[j];
+      }
+      Tens<T> n;
+      n(0, 0) = w[0]; n(1, 1) = w[1]; n(2, 2) = w[2];
+      n(0, 1) = n(1, 0) = w[3]; n(1, 2) = n(2, 1) = w[4]; n(0, 2) = n(2, 0) = w[5];
+      return n;
+    };
+    return this->finish(g, phi, flow_stress, normal, force_path, path_in);
+  }
+};
+
 // hyper_J2.cpp (zeta SYM_TENSOR, Ie SCALAR, alpha SCALAR; params E nu Y S D A n K)
 template <class T> struct HyperJ2 : Local<T> {
   HyperJ2() { this->nres = 3; this->neq[0] = 6; this->neq[1] = 1; this->neq[2] = 1; this->finish_layout(); }
@@ -2071,6 +2512,9 @@ template <class T> Local<T>* make_local(std::string const& type, int ndims = 3) 
   if (type == "small_hill") return new SmallHill<T>();
   if (type == "isotropic_elastic") return new IsotropicElastic<T>();
   if (type == "hypo_hill") return new HypoHill<T>();
+  if (type == "small_hosford") return new SmallHosford<T>();
+  if (type == "hypo_hosford") return new HypoHosford<T>();
+  if (type == "hypo_barlat") return new HypoBarlat<T>();
   return nullptr;
 }
 
@@ -2775,6 +3219,14 @@ int c8o_nloc(void* h) { return ((Ctx*)h)->nloc; }
 int c8o_ndims(void* h) { return ((Ctx*)h)->ndims; }
 int c8o_nres(void* h) { return ((Ctx*)h)->nres; }
 void c8o_set_thickness(void* h, double t) { ((Ctx*)h)->thickness = t; }
+// the `line search:` sublist of a local residual (line_search.hpp:40-49; the Hosford / Barlat models use it)
+void c8o_set_local_line_search(void* h, double c1, double bmin, double bmax, int max_evals) {
+  Ctx* c = (Ctx*)h;
+  LineSearchParams p;
+  p.c1 = c1; p.backtrack_min = bmin; p.backtrack_max = bmax; p.max_evals = max_evals;
+  c->local_d->ls = p;
+  c->local_f->ls = p;
+}
 int c8o_npts(void* h) { return ((Ctx*)h)->ngpts; }
 void c8o_set_params(void* h, double const* params) {
   Ctx* c = (Ctx*)h;

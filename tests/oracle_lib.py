@@ -43,6 +43,7 @@ def lib():
         L.c8o_ndims.argtypes = [C.c_void_p]
         L.c8o_nres.argtypes = [C.c_void_p]
         L.c8o_set_thickness.argtypes = [C.c_void_p, C.c_double]
+        L.c8o_set_local_line_search.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
         L.c8o_npts.argtypes = [C.c_void_p]
         L.c8o_set_params.argtypes = [C.c_void_p, dp]
         L.c8o_set_active.argtypes = [C.c_void_p, C.c_int, C.c_int, ip]
@@ -144,6 +145,10 @@ class Oracle:
         if getattr(self, "h", None):
             self.L.c8o_destroy(self.h)
             self.h = None
+
+    def set_local_line_search(self, c1=1e-4, bmin=0.5, bmax=0.9, max_evals=4):
+        """the `line search:` sublist of the local residual (Hosford / Barlat models); defaults of line_search.hpp:28-35"""
+        self.L.c8o_set_local_line_search(self.h, c1, bmin, bmax, int(max_evals))
 
     def set_thickness(self, t):
         self.L.c8o_set_thickness(self.h, float(t))

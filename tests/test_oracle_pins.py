@@ -121,6 +121,38 @@ def test_notch_hypo_J2_deck_is_hypo_hill(notch):
     assert pr.xi[-1][:, :, 6].max() > 1e-2
 
 
+BARLAT_6111_T4 = [70e3, 0.3, 200.0, 8.0, 0.0, 200.0, 20.0,  # E nu Y a K S D, then sp_01 .. sp_55 and dp_01 .. dp_55
+                  1.241024, 1.078271, 1.216463, 1.223867, 1.093105, 0.889161, 0.501909, 0.557173, 1.349094,
+                  0.775366, 0.922743, 0.765487, 0.793356, 0.918689, 1.027625, 1.115833, 1.112273, 0.589787]
+
+
+def test_notch_small_hosford(notch):
+    # primal/notch_small_hosford.yaml.in: `small_hosford` with exponent a = 100 (:26-34), local line search with 100
+    # evaluations (:25-30), 4 steps, ymax pulled by 0.001*t; pin :50-51.  Exercises minitensor::eig_spd_cos (restated from
+    # the published algorithm: Trilinos is not in /root/reference) with derivatives flowing through it, Hosford's yield
+    # function on the principal stresses and the local Newton iteration with a forced branch and the cubic line search.
+    be = ol.Oracle(ol.TET4, notch["coords"], notch["conn"], "small_hosford", [1000.0, 0.25, 2.0, 100.0, 0.0, 10.0, 2.0],
+                   max_iters=500, abs_tol=1e-12, rel_tol=1e-12)
+    be.set_local_line_search(1e-4, 0.5, 0.9, 100)
+    dbcs = sym_dbcs(notch) + [Dbc(0, 1, notch["node_sets"]["ymax"], lambda x, y, z, t: 0.001 * t)]
+    pr = Primal(be, notch["coords"], dbcs, max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 1.4447629888205869e-04) < 1.0e-7, pr.qoi()  # deck tolerance 1e-4; measured 2.1e-9
+    assert pr.xi[-1][:, :, 6].max() > 1e-2
+
+
+def test_notch_hypo_barlat(notch):
+    # primal/notch_hypo_barlat.yaml.in: `hypo_barlat` (Yld2004-18p, 6111-T4 aluminium, a = 8; :31-57), local line search,
+    # 4 steps, ymax pulled by 0.01*t; pin :70-71.  Two eigen-decompositions per evaluation, the 6 x 6 linear
+    # transformations, the hypoelastic update; hypo_hosford.cpp is this class with Hosford's function of the test above.
+    be = ol.Oracle(ol.TET4, notch["coords"], notch["conn"], "hypo_barlat", BARLAT_6111_T4, max_iters=500, abs_tol=1e-12,
+                   rel_tol=1e-12)
+    be.set_local_line_search(1e-4, 0.5, 0.9, 100)
+    dbcs = sym_dbcs(notch) + [Dbc(0, 1, notch["node_sets"]["ymax"], lambda x, y, z, t: 0.01 * t)]
+    pr = Primal(be, notch["coords"], dbcs, max_iters=15, abs_tol=1e-8, rel_tol=1e-8).solve(4)
+    assert rel(pr.qoi(), 1.3989452247489746e-03) < 1.0e-10, pr.qoi()  # deck tolerance 1e-4; measured 1.6e-13
+    assert pr.xi[-1][:, :, 6].max() > 0.1
+
+
 @pytest.fixture(scope="module")
 def notch2d():
     d = json.load(open(os.path.join(HERE, "golden", "notch2D_tri3.json")))
