@@ -61,7 +61,7 @@ class LinearSystem:
 class Assembler:
     def __init__(self, elem_type, coords, conn, local_type, params, elem_set=None, stab_mult=1.0, max_iters=500,
                  abs_tol=1e-12, rel_tol=1e-12, device="cuda:0", scatter=None, extra_pairs=None, global_type=None,
-                 thickness=0.0):
+                 thickness=0.0, line_search=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("calibr8_amd needs a HIP device: there is no CPU execution path")
@@ -87,7 +87,9 @@ class Assembler:
         if global_type is None:  # the pairing of the reference's decks
             global_type = "mechanics_plane_stress" if local_type.endswith("_plane_stress") else "mechanics"
         mo = _l.ModelDesc(global_type.encode(), local_type.encode(), stab_mult, max_iters, abs_tol, rel_tol,
-                          self.params.shape[1], self.params.ctypes.data_as(_l.dp), float(thickness))
+                          self.params.shape[1], self.params.ctypes.data_as(_l.dp), float(thickness),
+                          *((0.0, 0.0, 0.0, 0) if line_search is None else  # (c1, min factor, max factor, max evals)
+                            (float(line_search[0]), float(line_search[1]), float(line_search[2]), int(line_search[3]))))
         h = C.c_void_p()
         _l.check(self.L.c8_create(C.byref(md), C.byref(mo), C.byref(h)))
         self.h = h

@@ -56,6 +56,9 @@ static int model_id(char const* name, int ndims, int* nloc, int* nparams) {
   if (s == "isotropic_elastic") { *nloc = IsotropicElastic<double>::NLOC; *nparams = IsotropicElastic<double>::NPARAMS; return MODEL_ISOTROPIC_ELASTIC; }
   if (s == "hypo_hill") { *nloc = HypoHill<double>::NLOC; *nparams = HypoHill<double>::NPARAMS; return MODEL_HYPO_HILL; }
   if (s == "small_hill") { *nloc = SmallHill<double>::NLOC; *nparams = SmallHill<double>::NPARAMS; return MODEL_SMALL_HILL; }
+  if (s == "small_hosford") { *nloc = SmallHosford<double>::NLOC; *nparams = SmallHosford<double>::NPARAMS; return MODEL_SMALL_HOSFORD; }
+  if (s == "hypo_hosford") { *nloc = HypoHosford<double>::NLOC; *nparams = HypoHosford<double>::NPARAMS; return MODEL_HYPO_HOSFORD; }
+  if (s == "hypo_barlat") { *nloc = HypoBarlat<double>::NLOC; *nparams = HypoBarlat<double>::NPARAMS; return MODEL_HYPO_BARLAT; }
   return MODEL_NONE;
 }
 
@@ -141,6 +144,14 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   c->ms = ModelSettings{mo->stabilization_multiplier, mo->local_abs_tol, mo->local_rel_tol, mo->local_max_iters,
                         mo->thickness > 0. ? mo->thickness : 1.};
   c->nres = model_is_plane_stress(model) ? 1 : 2;
+  if (mo->ls_max_evals < 0 || mo->ls_sufficient_decrease < 0. || mo->ls_min_backtrack < 0. || mo->ls_max_backtrack < 0.) {
+    delete c;
+    return fail(C8_ERR_ARG, "c8_create: negative line-search setting");
+  }
+  if (mo->ls_sufficient_decrease > 0.) c->ms.ls_c1 = mo->ls_sufficient_decrease;  // 0: the defaults of line_search.hpp:28-35
+  if (mo->ls_min_backtrack > 0.) c->ms.ls_bmin = mo->ls_min_backtrack;
+  if (mo->ls_max_backtrack > 0.) c->ms.ls_bmax = mo->ls_max_backtrack;
+  if (mo->ls_max_evals > 0) c->ms.ls_max_evals = mo->ls_max_evals;
   c->params.assign(mo->params, mo->params + (size_t)md->num_elem_sets * nparams);
   c->active.assign(md->num_elem_sets, std::vector<int32_t>());
   c->active[0].push_back(0);  // default: E of element set 0 (small_J2.cpp:96-98)
@@ -235,6 +246,9 @@ int c8_init_variables(const c8_ctx* c, double* xi) {
       case MODEL_SMALL_HILL: SmallHill<double>::init_variables(x); break;
       case MODEL_ISOTROPIC_ELASTIC: IsotropicElastic<double>::init_variables(x); break;
       case MODEL_HYPO_HILL: HypoHill<double>::init_variables(x); break;
+      case MODEL_SMALL_HOSFORD: SmallHosford<double>::init_variables(x); break;
+      case MODEL_HYPO_HOSFORD: HypoHosford<double>::init_variables(x); break;
+      case MODEL_HYPO_BARLAT: HypoBarlat<double>::init_variables(x); break;
       default: return fail(C8_ERR_UNSUPPORTED, "c8_init_variables: unknown model");
     }
   }
@@ -314,7 +328,7 @@ int c8_gather_finish(c8_ctx* c) {
 int c8_set_kernel_variant(c8_ctx* c, int variant) {
   if (!c || variant < C8_KERNEL_AUTO || variant > C8_KERNEL_WAVE) return fail(C8_ERR_ARG, "c8_set_kernel_variant: bad argument");
   if (variant == C8_KERNEL_WAVE && !c->ks.forward_jacobian_wave)
-    return fail(C8_ERR_UNSUPPORTED, "c8_set_kernel_variant: the wave-per-element kernel needs hex8 elements");
+    return fail(C8_ERR_UNSUPPORTED, "c8_set_kernel_variant: the wave-per-element kernels exist for hex8 elements and the models without a local line search");
   c->kernel_variant = variant;
   return C8_OK;
 }

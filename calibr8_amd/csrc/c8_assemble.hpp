@@ -50,6 +50,9 @@ struct ModelSettings {
   double abs_tol, rel_tol;
   int max_iters;
   double thickness = 1.;  // mechanics_plane_stress.cpp:22
+  // `line search:` sublist of the local residual (line_search.hpp:28-49; Hosford / Barlat models)
+  double ls_c1 = 1.e-4, ls_bmin = 0.5, ls_bmax = 0.9;
+  int ls_max_evals = 4;
 };
 struct FieldArgs {
   double const* u;        // [nnodes][3]
@@ -321,6 +324,12 @@ template <class E, template <class> class ModelT> struct ForwardLane {
   int iter;
   double R_norm_0;
   bool converged, failed;
+  // models with a local line search (uses_line_search): branch of the first evaluation, state of the search
+  int path;
+  double dxi[Model::NLOC];
+  double ls_alpha, ls_applied, ls_best_alpha, ls_best_phi, ls_phi0, ls_phi;
+  int ls_n;
+  bool ls_done;
 };
 
 template <class Model> C8_HD void load_params(Model& m, MeshTables const& mt, int e) {
@@ -452,6 +461,113 @@ C8_HD void scatter_rhs(EX& ex, SH const& sh, SystemArgs const& sa, GetR getr, in
   });
 }
 
+// ---- local Newton iteration with line search (small_hosford.cpp:147-218, hypo_hosford.cpp:183-254, hypo_barlat.cpp:
+// 353-432): the branch is chosen by the first evaluation and forced afterwards; every Newton step is followed by the
+// backtracking search of line_search.hpp:85-135 on the merit 1/2 |C|^2 with slope C . (J dxi).  All values are
+// replicated over the lanes of a group, so every lane takes the same decisions; lane c < NL holds column c of J = dC/dxi
+// in its tangents and hands it to the group through sh.M.  On exit sh.M holds dC/dxi of the last evaluation at the
+// converged state, as after the plain iteration.
+template <int NL, class EX, class SH>
+C8_HD void local_newton_line_search(EX& ex, SH& sh, ModelSettings const& ms) {
+  auto active = [&](int k) { auto& r = ex.lane(k); return (r.iter <= ms.max_iters) && !r.converged; };
+  auto searching = [&](int k) { return active(k) && !ex.lane(k).ls_done; };
+  while (ex.any(active)) {
+    ex.each([&](int k) {
+      auto& r = ex.lane(k);
+      if (!active(k)) return;
+      if (r.iter == 1) r.path = r.m.evaluate(r.g, ms.abs_tol);
+      else r.m.evaluate(r.g, ms.abs_tol, true, r.path);
+      double nrm = 0.;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
+      double const C_norm = sqrt(nrm);
+      if (r.iter == 1) r.R_norm_0 = C_norm;
+      double const C_norm_rel = C_norm / r.R_norm_0;
+      if ((C_norm_rel < ms.rel_tol) || (C_norm < ms.abs_tol)) r.converged = true;
+      if (k < NL) C8_UNROLL for (int j = 0; j < NL; ++j) sh.M[j][k] = r.m.R[j].d;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].v;
+      r.ls_phi0 = 0.5 * C_norm * C_norm;
+    });
+    ex.sync();
+    if (!ex.any(active)) break;
+    bool const ok = gj_solve<NL>(ex, sh, [&](int k) { return ex.lane(k).b; });
+    ex.each([&](int k) {
+      auto& r = ex.lane(k);
+      if (!active(k)) return;
+      if (!ok) { r.failed = true; r.iter = ms.max_iters + 1; r.ls_done = true; return; }
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) { r.dxi[j] = r.b[j]; r.m.xi[j].v += r.b[j]; }  // the full Newton step
+      r.ls_alpha = 1.;
+      r.ls_applied = 1.;
+      r.ls_best_alpha = 1.;
+      r.ls_best_phi = 1.7976931348623157e308;
+      r.ls_n = 1;
+      r.ls_done = false;
+    });
+    while (ex.any(searching)) {
+      ex.each([&](int k) {  // eval(alpha): move to the trial step, evaluate on the forced branch
+        auto& r = ex.lane(k);
+        if (!searching(k)) return;
+        double const diff = r.ls_alpha - r.ls_applied;
+        r.ls_applied = r.ls_alpha;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.m.xi[j].v += diff * r.dxi[j];
+        r.path = r.m.evaluate(r.g, ms.abs_tol, true, r.path);
+        double nrm = 0.;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
+        double const C_alpha = sqrt(nrm);
+        r.ls_phi = 0.5 * C_alpha * C_alpha;
+        if (k < NL) C8_UNROLL for (int j = 0; j < NL; ++j) sh.M[j][k] = r.m.R[j].d;
+      });
+      ex.sync();
+      ex.each([&](int k) {
+        auto& r = ex.lane(k);
+        if (!searching(k)) return;
+        double slope = 0.;  // phi'(alpha) = C . (J dxi)
+        C8_UNROLL
+        for (int i = 0; i < NL; ++i) {
+          double Jd = 0.;
+          C8_UNROLL
+          for (int c = 0; c < NL; ++c) Jd += sh.M[i][c] * r.dxi[c];
+          slope += r.m.R[i].v * Jd;
+        }
+        double const phi_0 = r.ls_phi0, dphi_0 = -2. * phi_0;
+        if (r.ls_phi < r.ls_best_phi) { r.ls_best_phi = r.ls_phi; r.ls_best_alpha = r.ls_alpha; }
+        if (r.ls_phi <= phi_0 + r.ls_alpha * (ms.ls_c1 * dphi_0)) { r.ls_done = true; return; }  // sufficient decrease
+        // minimiser of the cubic through (0, phi_0, dphi_0) and (alpha, phi, slope), safeguarded (line_search.hpp:56-66,:121-123)
+        double const a = r.ls_alpha;
+        double const d1 = dphi_0 + slope - 3. * (phi_0 - r.ls_phi) / (0. - a);
+        double const radicand = d1 * d1 - dphi_0 * slope;
+        double alpha_model = 0.5 * a;
+        if (!(radicand < 0.)) {
+          double const d2 = sqrt(radicand);
+          double const denom = slope - dphi_0 + 2. * d2;
+          if (denom != 0.) alpha_model = a - a * (slope + d2 - d1) / denom;
+        }
+        double const lo = ms.ls_bmin * a, hi = ms.ls_bmax * a;
+        r.ls_alpha = fmin(fmax(alpha_model, lo), hi);
+        r.ls_n++;
+        if (r.ls_n > ms.ls_max_evals) { r.ls_alpha = r.ls_best_alpha; r.ls_done = true; }  // the lowest-merit step
+      });
+      ex.sync();
+    }
+    ex.each([&](int k) {  // move the local state to the accepted step
+      auto& r = ex.lane(k);
+      if (!active(k) || r.failed) return;
+      double const diff = r.ls_alpha - r.ls_applied;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) r.m.xi[j].v += diff * r.dxi[j];
+      r.iter++;
+    });
+  }
+  ex.each([&](int k) {
+    auto& r = ex.lane(k);
+    if ((r.iter > ms.max_iters) && !r.converged) r.failed = true;
+  });
+}
+
 // =====================================================================================
 // K1: eval_forward_jacobian (evaluations.cpp:12-154) for one element.
 // =====================================================================================
@@ -496,7 +612,9 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           r.R_norm_0 = 1.;
           r.converged = !Model::HAS_LOCAL;
         });
-        if (Model::HAS_LOCAL) {
+        if constexpr (uses_line_search<Model>::value) {
+          local_newton_line_search<NL>(ex, sh, ms);
+        } else if (Model::HAS_LOCAL) {
           while (ex.any([&](int k) { Lane& r = ex.lane(k); return (r.iter <= ms.max_iters) && !r.converged; })) {
             ex.each([&](int k) {
               Lane& r = ex.lane(k);

@@ -473,20 +473,23 @@ template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
+  // models with a local line search (Hosford / Barlat) run through the lane-group kernels on every element type: the
+  // wave-per-element kernels carry their own Newton iteration and are not instantiated for them
+  using WK = std::conditional_t<uses_line_search<ModelT<Dual>>::value, WaveKernel<void, ModelT>, WaveKernel<E, ModelT>>;
   KernelSet ks;
   ks.forward_jacobian = &launch_forward<E, ModelT>;
-  ks.forward_jacobian_wave = WaveKernel<E, ModelT>::get();
-  ks.adjoint_jacobian_wave = WaveKernel<E, ModelT>::get_adjoint();
-  ks.adjoint_local_wave = WaveKernel<E, ModelT>::get_adjoint_local();
-  ks.param_gradient_wave = WaveKernel<E, ModelT>::get_param_gradient();
+  ks.forward_jacobian_wave = WK::get();
+  ks.adjoint_jacobian_wave = WK::get_adjoint();
+  ks.adjoint_local_wave = WK::get_adjoint_local();
+  ks.param_gradient_wave = WK::get_param_gradient();
   ks.residual = &launch_residual<E, ModelT>;
-  ks.residual_wave = WaveKernel<E, ModelT>::get_residual();
+  ks.residual_wave = WK::get_residual();
   ks.adjoint_jacobian = &launch_adjoint_jacobian<E, ModelT>;
   ks.adjoint_local = &launch_adjoint_local<E, ModelT>;
   ks.param_gradient = &launch_param_gradient<E, ModelT>;
-  ks.qoi = WaveKernel<E, ModelT>::get_qoi() ? WaveKernel<E, ModelT>::get_qoi() : &launch_qoi<E, ModelT>;
+  ks.qoi = WK::get_qoi() ? WK::get_qoi() : &launch_qoi<E, ModelT>;
   ks.qoi_slot = &launch_qoi<E, ModelT>;
-  ks.shape_tables = WaveKernel<E, ModelT>::shape_tables;
+  ks.shape_tables = WK::shape_tables;
   ks.shape_stride = SHAPE_STRIDE;
   ks.gather_rows = &launch_gather_rows<E>;
   ks.stage_stride = stage_stride<E>();
@@ -504,6 +507,9 @@ template <class E> static KernelSet kernel_set_for(int model) {
     case MODEL_SMALL_HILL: return kernel_set<E, SmallHill>();
     case MODEL_ISOTROPIC_ELASTIC: return kernel_set<E, IsotropicElastic>();
     case MODEL_HYPO_HILL: return kernel_set<E, HypoHill>();
+    case MODEL_SMALL_HOSFORD: return kernel_set<E, SmallHosford>();
+    case MODEL_HYPO_HOSFORD: return kernel_set<E, HypoHosford>();
+    case MODEL_HYPO_BARLAT: return kernel_set<E, HypoBarlat>();
   }
   return KernelSet{};
 }
@@ -525,7 +531,7 @@ static KernelSet kernel_set_2d(int model) {
 
 KernelSet get_kernels(int elem_type, int model) {
   if (elem_type == C8_TRI3) return kernel_set_2d(model);
-  if (model >= MODEL_SMALL_HILL_PLANE_STRAIN) return KernelSet{};  // the plane models exist on 2-D meshes only
+  if (model >= MODEL_SMALL_HILL_PLANE_STRAIN && model <= MODEL_HYPO_HILL_PLANE_STRESS) return KernelSet{};  // the plane models exist on 2-D meshes only
   if (elem_type == C8_HEX8) return kernel_set_for<Elem<C8_HEX8>>(model);
   if (elem_type == C8_TET4) return kernel_set_for<Elem<C8_TET4>>(model);
   return KernelSet{};

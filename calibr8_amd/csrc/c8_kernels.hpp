@@ -9,7 +9,8 @@ namespace c8 {
 
 enum { MODEL_NONE = -1, MODEL_ELASTIC = 0, MODEL_SMALL_J2 = 1, MODEL_HYPER_J2 = 2, MODEL_SMALL_HILL = 3, MODEL_ISOTROPIC_ELASTIC = 4, MODEL_HYPO_HILL = 5,
        MODEL_SMALL_HILL_PLANE_STRAIN = 6, MODEL_HYPER_J2_PLANE_STRAIN = 7, MODEL_HYPO_HILL_PLANE_STRAIN = 8,
-       MODEL_SMALL_HILL_PLANE_STRESS = 9, MODEL_HYPER_J2_PLANE_STRESS = 10, MODEL_HYPO_HILL_PLANE_STRESS = 11 };
+       MODEL_SMALL_HILL_PLANE_STRESS = 9, MODEL_HYPER_J2_PLANE_STRESS = 10, MODEL_HYPO_HILL_PLANE_STRESS = 11,
+       MODEL_SMALL_HOSFORD = 12, MODEL_HYPO_HOSFORD = 13, MODEL_HYPO_BARLAT = 14 };
 inline bool model_is_plane_stress(int m) { return m >= MODEL_SMALL_HILL_PLANE_STRESS && m <= MODEL_HYPO_HILL_PLANE_STRESS; }
 
 struct LaunchArgs {

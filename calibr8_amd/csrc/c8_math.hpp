@@ -115,6 +115,12 @@ C8_HD Dual c8_exp(Dual const& a) {
   return Dual(e, e * a.d);
 }
 C8_HD double c8_exp(double a) { return exp(a); }
+C8_HD Dual c8_log(Dual const& a) { return Dual(log(a.v), a.d / a.v); }
+C8_HD double c8_log(double a) { return log(a); }
+C8_HD Dual c8_cos(Dual const& a) { return Dual(cos(a.v), -sin(a.v) * a.d); }
+C8_HD double c8_cos(double a) { return cos(a); }
+C8_HD Dual c8_acos(Dual const& a) { return Dual(acos(a.v), -a.d / sqrt(1. - a.v * a.v)); }
+C8_HD double c8_acos(double a) { return acos(a); }
 C8_HD Dual c8_abs(Dual const& a) { return a.v >= 0. ? a : Dual(-a.v, -a.d); }
 C8_HD double c8_abs(double a) { return fabs(a); }
 // pow(a, b) with both arguments differentiable (Sacado's rule: zero derivative at a == 0).  Sacado drops the term of an
@@ -222,6 +228,121 @@ template <class T> C8_HD T norm(Tens3<T> const& A) {
               A.zx * A.zx + A.zy * A.zy + A.zz * A.zz;
   return c8_sqrt(s);
 }
+// ---------------------------------------------------------------------------
+// minitensor::eig_spd_cos (Trilinos MiniTensor, third party): closed-form eigen-decomposition of a symmetric 3 x 3 tensor
+// (Scherzinger & Dohrmann, CMAME 197 (2008) 4007-4015), restated from the published algorithm with the scalar type as a
+// template parameter, so that derivatives flow through it as in the reference: the most distinct eigenvalue D[2] from the
+// trigonometric solution of the characteristic equation of the deviator, its eigenvector from the column space of
+// (A' - D[2] I) by Gram-Schmidt with column pivoting, the other two from the 2 x 2 problem on the orthogonal complement.
+// An (almost) diagonal tensor returns V = I, D = diag(A) at once.  Eigenvectors are the COLUMNS of V.  Column choices
+// are selects, not indexed stores, so everything stays in registers.
+// ---------------------------------------------------------------------------
+template <class T> C8_HD T sel3(int k, T const& a, T const& b, T const& c) { return k == 0 ? a : (k == 1 ? b : c); }
+template <class T> C8_HD void eig_spd_cos(Tens3<T> const& A, Tens3<T>& V, T* D) {
+  double const off = val(A.xy) * val(A.xy) + val(A.xz) * val(A.xz) + val(A.yx) * val(A.yx) + val(A.yz) * val(A.yz) +
+                     val(A.zx) * val(A.zx) + val(A.zy) * val(A.zy);
+  if (sqrt(off) <= 2.220446049250313e-16) {
+    V = eye3<T>();
+    D[0] = A.xx; D[1] = A.yy; D[2] = A.zz;
+    return;
+  }
+  double const pi = 3.141592653589793238;
+  T const trA = (1. / 3.) * trace(A);
+  Tens3<T> Ap = A;
+  Ap.xx = A.xx - trA; Ap.yy = A.yy - trA; Ap.zz = A.zz - trA;
+  T const J2 = -(Ap.xx * Ap.yy + Ap.yy * Ap.zz + Ap.zz * Ap.xx) + Ap.xy * Ap.xy + Ap.yz * Ap.yz + Ap.zx * Ap.zx;
+  T const J3 = det(Ap);
+  if (val(J2) <= 1.e-30) {  // volumetric tensor
+    D[0] = trA; D[1] = trA; D[2] = trA;
+    V = eye3<T>();
+    return;
+  }
+  T const t1 = 3. / J2;
+  T const rhs = (J3 / 2.) * c8_sqrt(t1 * t1 * t1);
+  T theta = T(pi / 2. * (1. - (val(rhs) < 0. ? -1. : 1.)));
+  if (fabs(val(rhs)) <= 1.) theta = c8_acos(rhs);
+  T thetad3 = theta / 3.;
+  if (val(thetad3) > pi / 6.) thetad3 = thetad3 + 2. * pi / 3.;
+  T const lam = 2. * c8_cos(thetad3) * c8_sqrt(J2 / 3.);
+  // columns of R = A' - lam I
+  T c0[3] = {Ap.xx - lam, Ap.yx, Ap.zx}, c1[3] = {Ap.xy, Ap.yy - lam, Ap.zy}, c2[3] = {Ap.xz, Ap.yz, Ap.zz - lam};
+  T const a0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+  T const a1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+  T const a2 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
+  int k = 0;
+  if (val(a1) > val(a0)) k = 1;
+  if (val(a2) > val(sel3(k, a0, a1, a2))) k = 2;
+  T const nk = c8_sqrt(sel3(k, a0, a1, a2));
+  T s1[3], ca[3], cb[3];  // the dominant column, normalised, and the other two in the order (k+1, k+2) mod 3
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    s1[i] = sel3(k, c0[i], c1[i], c2[i]) / nk;
+    ca[i] = sel3(k, c1[i], c2[i], c0[i]);
+    cb[i] = sel3(k, c2[i], c0[i], c1[i]);
+  }
+  T const d0 = s1[0] * ca[0] + s1[1] * ca[1] + s1[2] * ca[2];
+  T const d1 = s1[0] * cb[0] + s1[1] * cb[1] + s1[2] * cb[2];
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) { ca[i] = ca[i] - d0 * s1[i]; cb[i] = cb[i] - d1 * s1[i]; }
+  T const b0 = ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2];
+  T const b1 = cb[0] * cb[0] + cb[1] * cb[1] + cb[2] * cb[2];
+  bool const p = fabs(val(b1)) > fabs(val(b0));
+  T const nk2 = c8_sqrt(p ? b1 : b0);
+  T s2[3];
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) s2[i] = (p ? cb[i] : ca[i]) / nk2;
+  // eigenvector of lam: s1 x s2
+  T v2[3] = {s1[1] * s2[2] - s1[2] * s2[1], s1[2] * s2[0] - s1[0] * s2[2], s1[0] * s2[1] - s1[1] * s2[0]};
+  T mag = c8_sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) v2[i] = v2[i] / mag;
+  // the 2 x 2 problem on span{s1, s2}
+  T ak[3], ak2[3];
+  ak[0] = Ap.xx * s1[0] + Ap.xy * s1[1] + Ap.xz * s1[2];
+  ak[1] = Ap.yx * s1[0] + Ap.yy * s1[1] + Ap.yz * s1[2];
+  ak[2] = Ap.zx * s1[0] + Ap.zy * s1[1] + Ap.zz * s1[2];
+  ak2[0] = Ap.xx * s2[0] + Ap.xy * s2[1] + Ap.xz * s2[2];
+  ak2[1] = Ap.yx * s2[0] + Ap.yy * s2[1] + Ap.yz * s2[2];
+  ak2[2] = Ap.zx * s2[0] + Ap.zy * s2[1] + Ap.zz * s2[2];
+  T rm00 = s1[0] * ak[0] + s1[1] * ak[1] + s1[2] * ak[2];
+  T const rm01 = s1[0] * ak2[0] + s1[1] * ak2[1] + s1[2] * ak2[2];
+  T rm11 = s2[0] * ak2[0] + s2[1] * ak2[1] + s2[2] * ak2[2];
+  T const b = 0.5 * (rm00 - rm11);
+  double const fac = val(b) < 0. ? -1. : 1.;
+  T const arg = b * b + rm01 * rm01;
+  T lam0;
+  if (val(arg) == 0.) lam0 = rm11 + b;
+  else lam0 = rm11 + b - fac * c8_sqrt(arg);
+  T const lam1 = rm00 + rm11 - lam0;
+  rm00 = rm00 - lam0;
+  rm11 = rm11 - lam0;
+  T const q0 = rm00 * rm00 + rm01 * rm01, q1 = rm01 * rm01 + rm11 * rm11;
+  bool const k3 = val(q1) > val(q0);
+  T m0 = k3 ? rm01 : rm00, m1 = k3 ? rm11 : rm01;
+  if (val(k3 ? q1 : q0) == 0.) { m0 = T(1.); m1 = T(0.); }
+  T v0[3];
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) v0[i] = m0 * s2[i] - m1 * s1[i];
+  mag = c8_sqrt(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]);
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) v0[i] = v0[i] / mag;
+  T v1[3] = {v0[1] * v2[2] - v0[2] * v2[1], v0[2] * v2[0] - v0[0] * v2[2], v0[0] * v2[1] - v0[1] * v2[0]};
+  mag = c8_sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
+  C8_UNROLL
+  for (int i = 0; i < 3; ++i) v1[i] = v1[i] / mag;
+  V.xx = v0[0]; V.yx = v0[1]; V.zx = v0[2];
+  V.xy = v1[0]; V.yy = v1[1]; V.zy = v1[2];
+  V.xz = v2[0]; V.yz = v2[1]; V.zz = v2[2];
+  D[0] = lam0 + trA; D[1] = lam1 + trA; D[2] = lam + trA;
+}
+// w (V e_c)(V e_c)^T added to S: the weighted eigen-dyad of column c
+template <class T> C8_HD void add_dyad_col(Tens3<T>& S, T const& w, Tens3<T> const& V, int c) {
+  T const x = sel3(c, V.xx, V.xy, V.xz), y = sel3(c, V.yx, V.yy, V.yz), z = sel3(c, V.zx, V.zy, V.zz);
+  S.xx = S.xx + w * (x * x); S.xy = S.xy + w * (x * y); S.xz = S.xz + w * (x * z);
+  S.yx = S.yx + w * (y * x); S.yy = S.yy + w * (y * y); S.yz = S.yz + w * (y * z);
+  S.zx = S.zx + w * (z * x); S.zy = S.zy + w * (z * y); S.zz = S.zz + w * (z * z);
+}
+
 // minitensor::polar_rotation (Trilinos MiniTensor, third party): the rotation R of F = R U by Newton's iteration
 // X <- (mu X + X^-T / mu) / 2 with Higham's 1-norm / infinity-norm scaling, differentiated through like any other
 // arithmetic (global_residual.hpp:302-305 calls it on the FAD deformation gradient).  The trip count depends on

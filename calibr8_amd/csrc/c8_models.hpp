@@ -928,6 +928,241 @@ template <class T> struct HypoHillPlaneStress {
   }
 };
 
+
+// =====================================================================================================================
+// Hosford / Barlat family: yield functions on principal stresses (minitensor::eig_spd_cos, restated in c8_math.hpp), a
+// local Newton iteration whose branch is chosen by the first evaluation and forced afterwards, and the cubic line search
+// of line_search.hpp after every step (LINE_SEARCH: the assembly kernels run local_newton_line_search for these models).
+// =====================================================================================================================
+template <class M, class = void> struct uses_line_search : std::false_type {};
+template <class M> struct uses_line_search<M, std::enable_if_t<M::LINE_SEARCH>> : std::true_type {};
+
+// small_hosford.cpp:228-265, hypo_hosford.cpp:264-301: phi = vm (1/2 sum |(s_i - s_j) / vm|^a)^(1/a) and its normal
+template <class T>
+C8_HD void hosford_phi_and_normal(Tens3<T> const& sigma, T const& vm_stress, T const& a, T& phi, Tens3<T>& n) {
+  Tens3<T> V;
+  T D[3];
+  eig_spd_cos(sigma, V, D);
+  T const e0 = D[0] / vm_stress, e1 = D[1] / vm_stress, e2 = D[2] / vm_stress;
+  phi = vm_stress * c8_pow(0.5 * (c8_pow(c8_abs(e0 - e1), a) + c8_pow(c8_abs(e1 - e2), a) + c8_pow(c8_abs(e2 - e0), a)), 1. / a);
+  T const q0 = D[0] / phi, q1 = D[1] / phi, q2 = D[2] / phi;
+  T const d01 = q0 - q1, d12 = q1 - q2, d20 = q2 - q0;
+  T const am2 = a - 2.;
+  T const f01 = d01 * c8_pow(c8_abs(d01), am2), f12 = d12 * c8_pow(c8_abs(d12), am2), f20 = d20 * c8_pow(c8_abs(d20), am2);
+  n = scale(0., sigma);
+  add_dyad_col(n, f01 - f20, V, 0);
+  add_dyad_col(n, f12 - f01, V, 1);
+  add_dyad_col(n, f20 - f12, V, 2);
+  n = scale(0.5, n);
+}
+
+// ---- small_hosford.cpp ---------------------------------------------------------------------------------------------
+template <class T> struct SmallHosford {
+  static constexpr int NLOC = 7, NPARAMS = 7;
+  static constexpr bool FINITE_DEF = false, HAS_LOCAL = true, LINE_SEARCH = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 1, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  using Trial = NoTrial;
+  C8_HD Trial trial(PointState<T> const&) const { return {}; }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const&) { return evaluate(g, abs_tol); }
+  T params[NPARAMS];  // E nu Y a K S D  (small_hosford.cpp:86-92)
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // pstrain(00,01,02,11,12,22), alpha
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  C8_HD void initial_guess(PointState<T> const&) {  // :143-151
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) set_val(xi[k], val(xi_prev[k]));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const {  // :356-368
+    T const mu = compute_mu(params[0], params[1]);
+    return scale(2. * mu, dev(small_strain(g.grad_u)) - sym6(xi));
+  }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {  // :343-353
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const { return compute_kappa(params[0], params[1]) * trace(small_strain(g.grad_u)); }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {  // :268-340
+    T const mu = compute_mu(params[0], params[1]);
+    T const Y = params[2], a = params[3], K = params[4], S = params[5], D = params[6];
+    T const alpha = xi[6], alpha_old = xi_prev[6];
+    Tens3<T> const s = dev_cauchy(g);
+    Tens3<T> sigma = s;
+    sigma.xx = s.xx - g.p; sigma.yy = s.yy - g.p; sigma.zz = s.zz - g.p;
+    T const vm_stress = 1.22474487139158904910 * norm(s);
+    T phi;
+    Tens3<T> n;
+    hosford_phi_and_normal(sigma, vm_stress, a, phi, n);
+    T const flow_stress = Y + K * alpha + S * (1. - c8_exp(-(D * alpha)));
+    T const f = (phi - flow_stress) / (2. * val(mu));
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = alpha - alpha_old;
+      pack_sym6(sym6(xi) - sym6(xi_prev) - scale(dgam, n), R);
+      R[6] = f;
+    } else {
+      C8_UNROLL
+      for (int k = 0; k < NLOC; ++k) R[k] = xi[k] - xi_prev[k];
+    }
+    return path;
+  }
+};
+
+// ---- hypo_hosford.cpp / hypo_barlat.cpp: the hypoelastic frame of hypo_hill.cpp (unrotated Cauchy stress TC, elastic
+//      predictor as the initial guess) with residual rows scaled by 1 / (2 mu) -- a differentiable scale here ------------
+template <class T, class Derived, int NP> struct HypoPrincipalBase {
+  static constexpr int NLOC = 7, NPARAMS = NP;
+  static constexpr bool FINITE_DEF = true, HAS_LOCAL = true, LINE_SEARCH = true;
+  static constexpr int WAVE_BLOCKS_PER_CU = 1, WAVE_BLOCKS_PER_CU_ADJ = 1;
+  static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
+  T params[NPARAMS];
+  T xi[NLOC], xi_prev[NLOC], R[NLOC];  // TC(00,01,02,11,12,22), alpha
+  C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }
+  struct Trial { T d[6]; };  // d = R^T sym((F - F_prev) F^-1) R (hypo_kinematics.hpp:11-18; material axes Q = I)
+  C8_HD Trial trial(PointState<T> const& g) const {
+    Tens3<T> const I = eye3<T>();
+    Tens3<T> const F = g.grad_u + I;
+    Tens3<T> const F_prev = g.grad_u_prev + I;
+    Tens3<T> const Rot = polar_rotation(F);
+    Tens3<T> const L = matmul(F - F_prev, inverse(F));
+    Tens3<T> const D = scale(0.5, L + transpose(L));
+    Trial t;
+    pack_sym6(matmul(matmul(transpose(Rot), D), Rot), t.d);
+    return t;
+  }
+  C8_HD void initial_guess(PointState<T> const& g) {  // hypo_hosford.cpp:166-181, hypo_barlat.cpp:336-351
+    double const E = val(params[0]), nu = val(params[1]);
+    double const lambda = compute_lambda(E, nu), mu = compute_mu(E, nu);
+    Trial const t = trial(g);
+    double const ltr = lambda * (val(t.d[0]) + val(t.d[3]) + val(t.d[5]));
+    C8_UNROLL
+    for (int k = 0; k < 6; ++k) set_val(xi[k], val(xi_prev[k]) + ((k == 0 || k == 3 || k == 5) ? ltr : 0.) + 2. * mu * val(t.d[k]));
+    set_val(xi[6], val(xi_prev[6]));
+  }
+  C8_HD Tens3<T> rotated_cauchy(PointState<T> const& g) const {
+    Tens3<T> const Rot = polar_rotation(g.grad_u + eye3<T>());
+    return matmul(matmul(Rot, sym6(xi)), transpose(Rot));
+  }
+  C8_HD Tens3<T> dev_cauchy(PointState<T> const& g) const { return dev(rotated_cauchy(g)); }
+  C8_HD Tens3<T> cauchy(PointState<T> const& g) const {
+    Tens3<T> s = dev_cauchy(g);
+    s.xx = s.xx - g.p; s.yy = s.yy - g.p; s.zz = s.zz - g.p;
+    return s;
+  }
+  C8_HD T hydro_cauchy(PointState<T> const& g) const { return trace(rotated_cauchy(g)) / 3.; }
+  C8_HD void cauchy_and_hydro(PointState<T> const& g, Tens3<T>& sigma, T& sigma_h) const {
+    Tens3<T> const RC = rotated_cauchy(g);
+    sigma_h = trace(RC) / 3.;
+    sigma = dev(RC);
+    sigma.xx = sigma.xx - g.p; sigma.yy = sigma.yy - g.p; sigma.zz = sigma.zz - g.p;
+  }
+  C8_HD T pressure_scale_factor() const { return compute_kappa(params[0], params[1]); }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, bool force_path = false, int path_in = 0) {
+    return evaluate(g, abs_tol, trial(g), force_path, path_in);
+  }
+  C8_HD int evaluate(PointState<T> const& g, double abs_tol, Trial const& tr, bool force_path = false, int path_in = 0) {
+    T const lambda = compute_lambda(params[0], params[1]);
+    T const mu = compute_mu(params[0], params[1]);
+    T const alpha = xi[6], alpha_old = xi_prev[6];
+    Tens3<T> const TC = sym6(xi);
+    Derived& self = *static_cast<Derived*>(this);
+    T phi, flow_stress;
+    self.yield(TC, alpha, phi, flow_stress);
+    T const scale_factor = 2. * mu;
+    T const f = (phi - flow_stress) / scale_factor;
+    Tens3<T> const d = sym6(tr.d);
+    T const ltr = lambda * trace(d);
+    Tens3<T> Rt = TC - sym6(xi_prev);
+    Rt.xx = Rt.xx - ltr; Rt.yy = Rt.yy - ltr; Rt.zz = Rt.zz - ltr;
+    Rt = Rt - scale(2. * mu, d);
+    Rt = scale(1. / scale_factor, Rt);
+    int path;
+    if (!force_path) path = (val(f) > abs_tol || fabs(val(f)) < abs_tol) ? C8_PLASTIC_PATH : C8_ELASTIC_PATH;
+    else path = path_in;
+    if (path == C8_PLASTIC_PATH) {
+      T const dgam = alpha - alpha_old;
+      Rt = Rt + scale(dgam, self.normal(phi));  // the scale factor of the TC rows removes the 2 mu multiplier
+      R[6] = f;
+    } else {
+      R[6] = alpha - alpha_old;
+    }
+    pack_sym6(Rt, R);
+    return path;
+  }
+};
+
+// hypo_hosford.cpp (params E nu Y a K S D; the flow stress has no K term, :326)
+template <class T> struct HypoHosford : HypoPrincipalBase<T, HypoHosford<T>, 7> {
+  Tens3<T> n_;
+  C8_HD void yield(Tens3<T> const& TC, T const& alpha, T& phi, T& flow_stress) {
+    T const vm_stress = 1.22474487139158904910 * norm(dev(TC));
+    hosford_phi_and_normal(TC, vm_stress, this->params[3], phi, n_);
+    flow_stress = this->params[2] + this->params[5] * (1. - c8_exp(-(this->params[6] * alpha)));
+  }
+  C8_HD Tens3<T> normal(T const&) const { return n_; }
+};
+
+// hypo_barlat.cpp: Barlat's Yld2004-18p (yield_functions.hpp:101-386); params E nu Y a K S D sp_01 sp_02 sp_10 sp_12
+// sp_20 sp_21 sp_33 sp_44 sp_55 dp_01 .. dp_55
+template <class T> struct HypoBarlat : HypoPrincipalBase<T, HypoBarlat<T>, 25> {
+  Tens3<T> Vs_, Vd_;
+  T Ds_[3], Dd_[3];
+  // L * stress for the transformation built from nine coefficients q (unflatten_barlat_params :162-189); Voigt order
+  // (00, 11, 22, 01, 12, 20) (:128-141)
+  C8_HD static Tens3<T> transform(T const* q, Tens3<T> const& t) {
+    T const L00 = (q[0] + q[1]) / 3., L01 = (-2. * q[0] + q[1]) / 3., L02 = (q[0] - 2. * q[1]) / 3.;
+    T const L10 = (-2. * q[2] + q[3]) / 3., L11 = (q[2] + q[3]) / 3., L12 = (q[2] - 2. * q[3]) / 3.;
+    T const L20 = (-2. * q[4] + q[5]) / 3., L21 = (q[4] - 2. * q[5]) / 3., L22 = (q[4] + q[5]) / 3.;
+    Tens3<T> s;
+    s.xx = L00 * t.xx + L01 * t.yy + L02 * t.zz;
+    s.yy = L10 * t.xx + L11 * t.yy + L12 * t.zz;
+    s.zz = L20 * t.xx + L21 * t.yy + L22 * t.zz;
+    s.xy = s.yx = q[6] * t.xy;
+    s.yz = s.zy = q[7] * t.yz;
+    s.xz = s.zx = q[8] * t.zx;
+    return s;
+  }
+  C8_HD void yield(Tens3<T> const& TC, T const& alpha, T& phi, T& flow_stress) {  // evaluate_barlat_phi :322-366
+    T const a = this->params[3];
+    double const vm_phi = 1.22474487139158904910 * val(norm(dev(TC)));
+    eig_spd_cos(transform(&this->params[7], TC), Vs_, Ds_);
+    eig_spd_cos(transform(&this->params[16], TC), Vd_, Dd_);
+    T sum = T(0.);
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i)
+      C8_UNROLL
+      for (int j = 0; j < 3; ++j) sum = sum + c8_pow(c8_abs(Ds_[i] / vm_phi - Dd_[j] / vm_phi), a);
+    sum = 0.25 * sum;
+    phi = vm_phi * c8_exp((1.0 / a) * c8_log(sum));
+    flow_stress = this->params[2] + this->params[4] * alpha + this->params[5] * (1. - c8_exp(-(this->params[6] * alpha)));
+  }
+  C8_HD Tens3<T> normal(T const& phi) const {  // evaluate_barlat_normal / compute_barlat_normal :293-320, :369-384
+    T const am2 = this->params[3] - 2.;
+    Tens3<T> sp_n = scale(0., Vs_), dp_n = scale(0., Vs_);
+    C8_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      T ms = T(0.), md = T(0.);
+      C8_UNROLL
+      for (int j = 0; j < 3; ++j) {
+        T const ds = Ds_[k] / phi - Dd_[j] / phi;
+        ms = ms + ds * c8_pow(c8_abs(ds), am2);
+        T const dd = Ds_[j] / phi - Dd_[k] / phi;
+        md = md + (-dd) * c8_pow(c8_abs(dd), am2);
+      }
+      add_dyad_col(sp_n, 0.25 * ms, Vs_, k);
+      add_dyad_col(dp_n, 0.25 * md, Vd_, k);
+    }
+    return transform(&this->params[7], sp_n) + transform(&this->params[16], dp_n);
+  }
+};
+
 // ---- hyper_J2.cpp -------------------------------------------------------------
 template <class T> struct HyperJ2 {
   static constexpr int NLOC = 8, NPARAMS = 8;

@@ -31,7 +31,9 @@ class MeshDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("global_type", C.c_char_p), ("local_type", C.c_char_p), ("stabilization_multiplier", C.c_double),
                 ("local_max_iters", C.c_int32), ("local_abs_tol", C.c_double), ("local_rel_tol", C.c_double),
-                ("num_params", C.c_int32), ("params", dp), ("thickness", C.c_double)]
+                ("num_params", C.c_int32), ("params", dp), ("thickness", C.c_double),
+                ("ls_sufficient_decrease", C.c_double), ("ls_min_backtrack", C.c_double), ("ls_max_backtrack", C.c_double),
+                ("ls_max_evals", C.c_int32)]
 
 
 class Dbc(C.Structure):

@@ -72,7 +72,7 @@ typedef struct {
                                        "mechanics_plane_stress" (mechanics_plane_stress.cpp: ONE residual, u; it pairs
                                        with the *_plane_stress local residuals and only with them) */
   const char* local_type;           /* "elastic" | "small_J2" | "hyper_J2" | "small_hill" | "isotropic_elastic" |
-                                       "hypo_hill"; on tri3 meshes "small_J2" | "small_hill_plane_strain" |
+                                       "hypo_hill" | "small_hosford" | "hypo_hosford" | "hypo_barlat"; on tri3 meshes "small_J2" | "small_hill_plane_strain" |
                                        "hyper_J2_plane_strain" | "hypo_hill_plane_strain", and under
                                        mechanics_plane_stress "small_hill_plane_stress" | "hyper_J2_plane_stress" |
                                        "hypo_hill_plane_stress" (the names of local_residual.cpp:893-933) */
@@ -82,12 +82,20 @@ typedef struct {
   double local_rel_tol;             /* "nonlinear relative tol" */
   int32_t num_params;               /* elastic 4 (E nu cte delta_T), small_J2 6 (E nu K Y cte delta_T),
                                        hyper_J2 8 (E nu Y S D A n K), small_hill / hypo_hill 11 (E nu Y R00 R11 R22
-                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu), small_hill_plane_strain /
+                                       R01 R02 R12 S D), isotropic_elastic 2 (E nu), small_hosford / hypo_hosford 7 (E nu Y a K S D),
+                                       hypo_barlat 25 (those seven + sp_01 sp_02 sp_10 sp_12 sp_20 sp_21 sp_33 sp_44 sp_55
+                                       and dp_01 .. dp_55), small_hill_plane_strain /
                                        hypo_hill_plane_strain 9 (E nu Y S D R00 R11 R22 R01), hyper_J2_plane_strain 6 (E nu K Y Y_inf delta),
                                        small_hill_plane_stress 9 (as plane strain), hyper_J2_plane_stress 8 (as hyper_J2),
                                        hypo_hill_plane_stress 13 (the nine + Q00 Q01 Q10 Q11) */
   const double* params;             /* [num_elem_sets][num_params] */
   double thickness;                 /* mechanics_plane_stress.cpp:22 "thickness"; 0 = the reference's default 1 */
+  /* `line search:` sublist of the local residual (line_search.hpp:40-49), used by the local Newton iteration of
+   * small_hosford / hypo_hosford / hypo_barlat; 0 in a field = the reference's default (1e-4, 0.5, 0.9, 4 evaluations) */
+  double ls_sufficient_decrease;
+  double ls_min_backtrack;
+  double ls_max_backtrack;
+  int32_t ls_max_evals;
 } c8_model_desc;
 
 /* Primal state at one load step (DEVICE pointers).  Under mechanics_plane_stress (c8_num_residuals() == 1) the entries

@@ -279,8 +279,18 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
   else if (model == "small_hill") run<E, SmallHill>(c);
   else if (model == "isotropic_elastic") run<E, IsotropicElastic>(c);
   else if (model == "hypo_hill") run<E, HypoHill>(c);
+  else if (model == "small_hosford") run<E, SmallHosford>(c);
+  else if (model == "hypo_hosford") run<E, HypoHosford>(c);
+  else if (model == "hypo_barlat") run<E, HypoBarlat>(c);
   else return -2;
   return 0;
+}
+
+// the `line search:` settings of the local residual (c8_model_desc.ls_*): one configuration, like the objective
+static double g_ls_c1 = 1.e-4, g_ls_bmin = 0.5, g_ls_bmax = 0.9;
+static int g_ls_max_evals = 4;
+extern "C" void c8emu_set_local_line_search(double c1, double bmin, double bmax, int max_evals) {
+  g_ls_c1 = c1; g_ls_bmin = bmin; g_ls_bmax = bmax; g_ls_max_evals = max_evals;
 }
 
 // ptrs: 0 u, 1 p, 2 u_prev, 3 p_prev, 4 xi_prev, 5 xi, 6..9 A00 A01 A10 A11, 10 b0, 11 b1,
@@ -322,6 +332,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
     c.mt.shape = shape_tab.data();
   }
   c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
+  c.ms.ls_c1 = g_ls_c1; c.ms.ls_bmin = g_ls_bmin; c.ms.ls_bmax = g_ls_bmax; c.ms.ls_max_evals = g_ls_max_evals;
   c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
   c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};
   c.aa = AdjointArgs{ptrs[12], ptrs[13], ptrs[14], ptrs[15], ptrs[16], ptrs[17], active, QoiArgs{1., 0., 0, nullptr, elem_type == C8_TRI3 ? 2. : 3.}};

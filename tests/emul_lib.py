@@ -48,6 +48,11 @@ class Emul:
         self.wave = False  # True: K1 through the wave-per-element kernel (hex8 only)
         self.staged = False  # staged (gather) assembly of the two Jacobian kernels (hex8 slot K3 excepted)
         self.assign = False  # staged assembly: assign A and b instead of adding (c8_set_assign_mode)
+        self.ls = (1e-4, 0.5, 0.9, 4)  # local line search (Hosford / Barlat models): defaults of line_search.hpp:28-35
+
+    def set_local_line_search(self, c1=1e-4, bmin=0.5, bmax=0.9, max_evals=4):
+        self.ls = (c1, bmin, bmax, int(max_evals))
+        self.orc.set_local_line_search(*self.ls)
 
     def new_state(self):
         return self.orc.new_state()
@@ -69,6 +74,8 @@ class Emul:
     def _call(self, what, ptrs):
         o = self.orc
         self._push_objective()
+        lib().c8emu_set_local_line_search.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+        lib().c8emu_set_local_line_search(*self.ls)
         arr = (dp * 18)()
         for k, a in ptrs.items():
             arr[k] = a.ctypes.data_as(dp)

@@ -23,6 +23,16 @@ ACTIVE = {"small_J2": [0, 1, 2, 3], "elastic": [0, 1], "hyper_J2": [0, 1, 2, 3, 
           "hypo_hill": [0, 2, 3, 6, 9, 10], "small_hill_plane_strain": [0, 2, 3, 4, 5, 8], "hyper_J2_plane_strain": [0, 1, 2, 3, 4, 5],
           "hypo_hill_plane_strain": [0, 2, 3, 4, 5, 8], "small_hill_plane_stress": [0, 2, 3, 4, 5, 8],
           "hyper_J2_plane_stress": [0, 1, 2, 3, 4, 7], "hypo_hill_plane_stress": [0, 2, 3, 8, 9, 12]}
+# Hosford / Barlat family (3-D): yield functions on principal stresses, local Newton iteration with line search
+HOSFORD = [1000.0, 0.25, 2.0, 8.0, 50.0, 10.0, 2.0]        # E nu Y a K S D
+HOSFORD_100 = [1000.0, 0.25, 2.0, 100.0, 0.0, 10.0, 2.0]   # the exponent of notch_small_hosford.yaml.in
+BARLAT = [70e3, 0.3, 200.0, 8.0, 100.0, 200.0, 20.0,       # E nu Y a K S D + Yld2004-18p coefficients of 6111-T4 aluminium
+          1.241024, 1.078271, 1.216463, 1.223867, 1.093105, 0.889161, 0.501909, 0.557173, 1.349094,
+          0.775366, 0.922743, 0.765487, 0.793356, 0.918689, 1.027625, 1.115833, 1.112273, 0.589787]
+LOCAL_LINE_SEARCH = (1e-4, 0.5, 0.9, 100)  # the `line search:` sublist of the two decks
+CASES_LINE_SEARCH = [("small_hosford", HOSFORD, 0.004), ("small_hosford", HOSFORD_100, 0.004), ("hypo_hosford", HOSFORD, 0.004),
+                     ("hypo_barlat", BARLAT, 0.006)]
+ACTIVE.update({"small_hosford": [0, 1, 2, 3, 5, 6], "hypo_hosford": [0, 1, 2, 3, 5, 6], "hypo_barlat": [0, 2, 3, 7, 13, 16, 22, 24]})
 # 2-D (tri3) cases: the models of the reference's 2-D decks that run on `mechanics` with 2 + 1 equations per node
 HILL_PS = [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.1, 0.9, 1.05]  # E nu Y S D R00 R11 R22 R01
 HJ2_PS = [1000.0, 0.25, 100.0, 2.0, 3.0, 40.0]  # E nu K Y Y_inf delta

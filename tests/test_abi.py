@@ -68,7 +68,7 @@ def test_no_cpu_fallback():
     assert rc == lib.C8_ERR_DEVICE and not h.value
     assert b"no HIP device" in L.c8_last_error()
     # argument checking
-    mo2 = lib.ModelDesc(b"mechanics", b"hypo_barlat", 1.0, 10, 1e-12, 1e-12, 6, params.ctypes.data_as(lib.dp))
+    mo2 = lib.ModelDesc(b"mechanics", b"no_such_model", 1.0, 10, 1e-12, 1e-12, 6, params.ctypes.data_as(lib.dp))
     assert L.c8_create(C.byref(md), C.byref(mo2), C.byref(h)) == lib.C8_ERR_UNSUPPORTED
     assert b"unknown local residual name" in L.c8_last_error()
 
