@@ -183,6 +183,11 @@ C8_HD double interp_ab(SH const& sh, int pt, int a, int b, double const* u3 /* [
   return s;
 }
 
+#ifdef C8_TUNE_ALWAYS_SWAP  // tuning build (same results): the row-exchange selects of the local solves run unconditionally
+#define C8_ALWAYS_SWAP true
+#else
+#define C8_ALWAYS_SWAP false
+#endif
 // Gauss-Jordan with row pivoting inside lane groups of G lanes (see gj_solve in c8_assemble.hpp for the slot kernels).
 // Lane cg (< NL) of a group owns COLUMN cg of the group's matrix in its registers (col(lane, r), r = 0..NL-1) and every
 // lane of the group carries its own right-hand side b (registers).  Step s: the owner of column s publishes it through
@@ -221,16 +226,18 @@ C8_HD bool gj_solve_cols(EX& ex, GetM getm, Col col, GetB getb, Active active) {
       bool const mine = cg > s && cg < NL;  // this lane still has a column to eliminate
       double const cs = pc[s], bs = b[s], ms = col(lane, s);
       double cpiv = cs, bpiv = bs, mpiv = ms;
-      static_for<NL>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        bool const hit = (r > s) && (r == rstar);
-        cpiv = hit ? pc[r] : cpiv;
-        bpiv = hit ? b[r] : bpiv;
-        mpiv = hit ? col(lane, r) : mpiv;
-        pc[r] = hit ? cs : pc[r];
-        b[r] = hit ? bs : b[r];
-        col(lane, r) = hit ? ms : col(lane, r);
-      });
+      if (ex.uniform_any(rstar != s) || C8_ALWAYS_SWAP) {  // row exchanges are rare (never needed by the J2 models): skipped wave-wide when no group pivots
+        static_for<NL>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          bool const hit = (r > s) && (r == rstar);
+          cpiv = hit ? pc[r] : cpiv;
+          bpiv = hit ? b[r] : bpiv;
+          mpiv = hit ? col(lane, r) : mpiv;
+          pc[r] = hit ? cs : pc[r];
+          b[r] = hit ? bs : b[r];
+          col(lane, r) = hit ? ms : col(lane, r);
+        });
+      }
       double const inv = 1. / cpiv;
       double const bsn = bpiv * inv;
       b[s] = bsn;
@@ -277,16 +284,18 @@ C8_HD bool gj_solve_xlane(EX& ex, Col col, GetB getb, Active active) {
       bool const mine = cg > s && cg < NL;  // this lane still has a column to eliminate
       double const cs = pc[s], bs = b[s], ms = col(lane, s);
       double cpiv = cs, bpiv = bs, mpiv = ms;
-      static_for<NL>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        bool const hit = (r > s) && (r == rstar);
-        cpiv = hit ? pc[r] : cpiv;
-        bpiv = hit ? b[r] : bpiv;
-        mpiv = hit ? col(lane, r) : mpiv;
-        pc[r] = hit ? cs : pc[r];
-        b[r] = hit ? bs : b[r];
-        col(lane, r) = (hit && mine) ? ms : col(lane, r);  // the owner of the pivot column leaves it as broadcast
-      });
+      if (ex.uniform_any(rstar != s) || C8_ALWAYS_SWAP) {  // see gj_solve_cols
+        static_for<NL>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          bool const hit = (r > s) && (r == rstar);
+          cpiv = hit ? pc[r] : cpiv;
+          bpiv = hit ? b[r] : bpiv;
+          mpiv = hit ? col(lane, r) : mpiv;
+          pc[r] = hit ? cs : pc[r];
+          b[r] = hit ? bs : b[r];
+          col(lane, r) = (hit && mine) ? ms : col(lane, r);  // the owner of the pivot column leaves it as broadcast
+        });
+      }
       double const inv = 1. / cpiv;
       double const bsn = bpiv * inv;
       b[s] = bsn;
@@ -305,11 +314,14 @@ C8_HD bool gj_solve_xlane(EX& ex, Col col, GetB getb, Active active) {
   return ok;
 }
 
+// hand-over of the Newton solve of K1: GJ_XLANE_NEWTON where a model names it, else the model's GJ_XLANE_JAC
+template <class M, class = void> struct xlane_newton : std::integral_constant<bool, M::GJ_XLANE_JAC> {};
+template <class M> struct xlane_newton<M, std::void_t<decltype(M::GJ_XLANE_NEWTON)>> : std::integral_constant<bool, M::GJ_XLANE_NEWTON> {};
 #ifdef C8_TUNE_XL  // tuning build (same results): hand-over of the Newton solve (bit 0) and of the inverse (bit 1), every model
 #define C8_XL_NEWTON(M) ((C8_TUNE_XL & 1) != 0)
 #define C8_XL_INVERSE(M) ((C8_TUNE_XL & 2) != 0)
 #else
-#define C8_XL_NEWTON(M) M::GJ_XLANE_JAC
+#define C8_XL_NEWTON(M) xlane_newton<M>::value
 #define C8_XL_INVERSE(M) M::GJ_XLANE_JAC
 #endif
 // the local solve of the wave kernels: column d of the matrix is lane d's R[.].d, the right-hand side is lane.b

@@ -23,6 +23,9 @@ template <class Lane> struct GpuExec {
   __device__ __forceinline__ Lane& lane(int) { return L; }
   template <class F> __device__ __forceinline__ bool any(F f) { return f(k); }
   template <class F> __device__ __forceinline__ bool any_wave(F f) { return __any(f(k)) != 0; }
+  // callable INSIDE each(): true in every active lane if x is true in any of them -- a scalar branch around work that
+  // is a no-op for the lanes where x is false (the emulator simply returns x)
+  __device__ __forceinline__ bool uniform_any(bool x) { return __any(x) != 0; }
   // the value of f at the first active lane, in every lane
   template <class F> __device__ __forceinline__ int first_lane(F f) { return __builtin_amdgcn_readfirstlane(f(k)); }
   // Lanes of one wavefront exchange data through LDS.  LDS instructions of a wave execute in order, so

@@ -150,6 +150,7 @@ template <class T, int DIM> struct SmallJ2Dim {
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
   static constexpr int WAVE_BLOCKS_PER_CU_K4 = 3;  // 162 registers: three waves per SIMD (3.1 against 3.5 ms per million elements)
   static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = true;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
+  static constexpr bool GJ_XLANE_NEWTON = true;  // K1: DPP hand-over in the Newton solve, LDS in the inverse (11.35 against 11.47 ms per assembly, profiles/README round 2)
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }

@@ -30,6 +30,7 @@ template <class Lane, int NDOF> struct CpuExec {
   }
   template <class F> bool any(F f) { bool a = false; for (int k = 0; k < NDOF; ++k) { cur = k; a = f(k) || a; } cur = -1; return a; }
   template <class F> bool any_wave(F f) { return any(f); }
+  bool uniform_any(bool x) { return x; }
   template <class F> int first_lane(F f) { cur = 0; int const v = f(0); cur = -1; return v; }
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
