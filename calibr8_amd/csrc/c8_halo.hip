@@ -37,7 +37,6 @@ constexpr int TPB = 256;
 constexpr int NSEG = 6;                       // A00 A01 A10 A11 b0|x0 b1|x1
 constexpr int64_t OFF_MASK = ((int64_t)1 << 56) - 1;
 inline int64_t code(int seg, int64_t off) { return ((int64_t)seg << 56) | off; }
-inline int neq_of(int i) { return i == 0 ? 3 : 1; }
 
 #define C8H_HIP(call)                                                                                             \
   do {                                                                                                            \
@@ -144,6 +143,7 @@ struct c8_comm {
 struct c8_halo {
   int rank = 0, nranks = 1;
   int32_t nnodes = 0, nowned = 0, ntouched = 0;
+  int ndims = 3, nres = 2;               // equations per node of residual 0; residuals in the systems
   std::vector<int64_t> nodeptr;          // of the graph the tables were built from (checked at attach)
   Exchange full, bonly, aonly, import;   // C1+C2, C1, C2, C3
   // attached state
@@ -355,6 +355,11 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
   h->nnodes = num_nodes;
   h->nowned = d->num_owned;
   h->ntouched = d->num_touched;
+  h->ndims = d->num_dims == 0 ? 3 : d->num_dims;
+  h->nres = d->num_residuals == 0 ? 2 : d->num_residuals;
+  if ((h->ndims != 2 && h->ndims != 3) || (h->nres != 1 && h->nres != 2)) { delete h; return c8_fail(C8_ERR_ARG, "c8_halo_build: num_dims must be 2 or 3, num_residuals 1 or 2"); }
+  int const nres = h->nres, ndims = h->ndims;
+  auto neq_of = [ndims](int i) { return i == 0 ? ndims : 1; };
   h->nodeptr.assign(rowptr, rowptr + num_nodes + 1);
   auto bad = [&](std::string const& m) { delete h; return c8_fail(C8_ERR_ARG, "c8_halo_build: " + m); };
 
@@ -374,7 +379,7 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
       if (s1 < s0 || (s1 > s0 && !d->send_nodes)) return bad("send lists");
       size_t const before = x.send_idx.size();
       if (what & C8_HALO_B)
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < nres; ++i)
           for (int64_t q = s0; q < s1; ++q) {
             int32_t const n = d->send_nodes[q];
             if (n < d->num_owned || n >= d->num_touched) return bad("a send node is not a ghost node");
@@ -382,6 +387,7 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
           }
       if (what & C8_HALO_A)
         for (int b = 0; b < 4; ++b) {
+          if (blk[b][0] >= nres || blk[b][1] >= nres) continue;
           int const ni = neq_of(blk[b][0]), nj = neq_of(blk[b][1]);
           for (int64_t q = s0; q < s1; ++q) {
             int32_t const n = d->send_nodes[q];
@@ -396,7 +402,7 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
       if (r1 < r0 || (r1 > r0 && (!d->recv_nodes || !d->recv_cols))) return bad("recv lists");
       size_t const before_r = dst_of_pos.size();
       if (what & C8_HALO_B)
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < nres; ++i)
           for (int64_t q = r0; q < r1; ++q) {
             int32_t const n = d->recv_nodes[q];
             if (n < 0 || n >= d->num_owned) return bad("a recv node is not an owned node");
@@ -404,6 +410,7 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
           }
       if (what & C8_HALO_A)
         for (int b = 0; b < 4; ++b) {
+          if (blk[b][0] >= nres || blk[b][1] >= nres) continue;
           int const ni = neq_of(blk[b][0]), nj = neq_of(blk[b][1]);
           for (int64_t q = r0; q < r1; ++q) {
             int32_t const n = d->recv_nodes[q];
@@ -436,7 +443,7 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
     for (int r = 0; r < nranks; ++r) {
       int64_t const s0 = d->export_ptr[r], s1 = d->export_ptr[r + 1], r0 = d->import_ptr[r], r1 = d->import_ptr[r + 1];
       if (s1 < s0 || r1 < r0 || (s1 > s0 && !d->export_nodes) || (r1 > r0 && !d->import_nodes)) return bad("import / export lists");
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < nres; ++i) {
         for (int64_t q = s0; q < s1; ++q) {
           int32_t const n = d->export_nodes[q];
           if (n < 0 || n >= d->num_owned) return bad("an export node is not an owned node");
@@ -448,8 +455,9 @@ int c8_halo_build(int32_t num_nodes, const int64_t* rowptr, const int32_t* colid
           for (int a = 0; a < neq_of(i); ++a) x.dst.push_back(code(4 + i, (int64_t)n * neq_of(i) + a));
         }
       }
-      x.send_counts[r] = (s1 - s0) * 4;
-      x.recv_counts[r] = (r1 - r0) * 4;
+      int const per_node = ndims + (nres == 2 ? 1 : 0);
+      x.send_counts[r] = (s1 - s0) * per_node;
+      x.recv_counts[r] = (r1 - r0) * per_node;
     }
     x.nsend = (int64_t)x.send_idx.size();
     x.nrecv = (int64_t)x.dst.size();
@@ -488,7 +496,8 @@ int c8_halo_attach(c8_halo* h, c8_ctx* c, c8_comm* cm) {
   if (h->ctx) return c8_fail(C8_ERR_ARG, "c8_halo_attach: already attached");
   if (cm->rank != h->rank || cm->nranks != h->nranks) return c8_fail(C8_ERR_ARG, "c8_halo_attach: communicator rank / size differ from the halo's");
   if (c->mesh.nnodes != h->nnodes) return c8_fail(C8_ERR_ARG, "c8_halo_attach: the context has another number of nodes");
-  if (c->ndims != 3) return c8_fail(C8_ERR_UNSUPPORTED, "c8_halo_attach: the exchange tables are built for 3 + 1 equations per node (3-D meshes)");
+  if (c->ndims != h->ndims || c->nres != h->nres)
+    return c8_fail(C8_ERR_ARG, "c8_halo_attach: the tables were built for other systems (c8_halo_desc.num_dims / num_residuals against c8_num_dims / c8_num_residuals)");
   for (int32_t n = 0; n <= h->nnodes; ++n)
     if ((int64_t)c->graph.nodeptr[n] != h->nodeptr[n]) return c8_fail(C8_ERR_ARG, "c8_halo_attach: the context's graph is not the one the tables were built from");
   int rc;
@@ -528,8 +537,11 @@ void c8_halo_destroy(c8_halo* h) {
 int c8_halo_gather_start(c8_halo* h, const c8_system* sys, int what) {
   if (!h || !h->ctx || !sys) return c8_fail(C8_ERR_ARG, "c8_halo_gather_start: null argument or halo not attached");
   if (what < 1 || what > 3) return c8_fail(C8_ERR_ARG, "c8_halo_gather_start: what = C8_HALO_B | C8_HALO_A");
-  if ((what & C8_HALO_B) && (!sys->b[0] || !sys->b[1])) return c8_fail(C8_ERR_ARG, "c8_halo_gather_start: null b");
-  if ((what & C8_HALO_A) && (!sys->A[0][0] || !sys->A[0][1] || !sys->A[1][0] || !sys->A[1][1])) return c8_fail(C8_ERR_ARG, "c8_halo_gather_start: null A block");
+  for (int i = 0; i < h->nres; ++i) {
+    if ((what & C8_HALO_B) && !sys->b[i]) return c8_fail(C8_ERR_ARG, "c8_halo_gather_start: null b");
+    for (int j = 0; j < h->nres; ++j)
+      if ((what & C8_HALO_A) && !sys->A[i][j]) return c8_fail(C8_ERR_ARG, "c8_halo_gather_start: null A block");
+  }
   return start_exchange(h, what == 3 ? h->full : (what == 1 ? h->bonly : h->aonly), system_segs(sys));
 }
 int c8_halo_gather_finish(c8_halo* h, const c8_system* sys) {
@@ -541,7 +553,7 @@ int c8_halo_gather(c8_halo* h, const c8_system* sys, int what) {
   return rc ? rc : c8_halo_gather_finish(h, sys);
 }
 int c8_halo_scatter_x(c8_halo* h, double* const x[2]) {
-  if (!h || !h->ctx || !x || !x[0] || !x[1]) return c8_fail(C8_ERR_ARG, "c8_halo_scatter_x: null argument or halo not attached");
+  if (!h || !h->ctx || !x || !x[0] || (h->nres == 2 && !x[1])) return c8_fail(C8_ERR_ARG, "c8_halo_scatter_x: null argument or halo not attached");
   Segs const segs{{nullptr, nullptr, nullptr, nullptr, x[0], x[1]}};
   int const rc = start_exchange(h, h->import, segs);
   return rc ? rc : finish_exchange(h, segs);

@@ -218,8 +218,9 @@ class HaloPlan:
         assert (k < len(self._sorted_gid)).all() and (self._sorted_gid[np.minimum(k, len(self._sorted_gid) - 1)] == gids).all()
         return self._sorted[k].astype(np.int64)
 
-    def desc(self):
-        """c8_halo_desc over this plan's arrays (which it keeps alive)."""
+    def desc(self, ndims=3, nres=2):
+        """c8_halo_desc over this plan's arrays (which it keeps alive), for systems with `ndims` equations per node in
+        residual 0 and `nres` residuals"""
         a = lambda v, t: np.ascontiguousarray(v, dtype=t)
         keep = [a(self.send_ptr, np.int64), a(self.send_nodes, np.int32), a(self.recv_ptr, np.int64), a(self.recv_nodes, np.int32),
                 a(self.recv_col_ptr, np.int64), a(self.recv_cols, np.int32), a(self.import_ptr, np.int64), a(self.import_nodes, np.int32),
@@ -227,7 +228,7 @@ class HaloPlan:
         p64 = lambda v: v.ctypes.data_as(_l.i64p)
         p32 = lambda v: v.ctypes.data_as(_l.i32p)
         d = _l.HaloDesc(self.part.nowned, self.part.ntouched, p64(keep[0]), p32(keep[1]), p64(keep[2]), p32(keep[3]), p64(keep[4]),
-                        p32(keep[5]), p64(keep[6]), p32(keep[7]), p64(keep[8]), p32(keep[9]))
+                        p32(keep[5]), p64(keep[6]), p32(keep[7]), p64(keep[8]), p32(keep[9]), int(ndims), int(nres))
         d._keep = keep
         return d
 
@@ -308,14 +309,18 @@ class Halo:
     attached to an Assembler and a Comm for the run-time exchanges."""
     B, A = _l.C8_HALO_B, _l.C8_HALO_A
 
-    def __init__(self, plan, node_rowptr, node_colidx, asm=None, comm=None):
+    def __init__(self, plan, node_rowptr, node_colidx, asm=None, comm=None, ndims=None, nres=None):
         self.L = _l.load_library()
+        if ndims is None:  # the shape of the assembler's systems: 3 + 1 equations per node unless told otherwise
+            ndims = getattr(asm, "ndims", 3)
+        if nres is None:
+            nres = getattr(asm, "nres", 2)
         self.plan, self.world = plan, plan.world
         self.nowned = plan.part.nowned
         rp = np.ascontiguousarray(node_rowptr, dtype=np.int64)
         ci = np.ascontiguousarray(node_colidx, dtype=np.int32)
         assert len(rp) == plan.nnodes + 1
-        d = plan.desc()
+        d = plan.desc(ndims, nres)
         h = C.c_void_p()
         _l.check(self.L.c8_halo_build(plan.nnodes, rp.ctypes.data_as(_l.i64p), ci.ctypes.data_as(_l.i32p), C.byref(d),
                                       plan.part.rank if plan.world > 1 else 0, plan.world, C.byref(h)))

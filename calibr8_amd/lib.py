@@ -72,7 +72,8 @@ class HaloDesc(C.Structure):
     _fields_ = [("num_owned", C.c_int32), ("num_touched", C.c_int32),
                 ("send_ptr", i64p), ("send_nodes", i32p),
                 ("recv_ptr", i64p), ("recv_nodes", i32p), ("recv_col_ptr", i64p), ("recv_cols", i32p),
-                ("import_ptr", i64p), ("import_nodes", i32p), ("export_ptr", i64p), ("export_nodes", i32p)]
+                ("import_ptr", i64p), ("import_nodes", i32p), ("export_ptr", i64p), ("export_nodes", i32p),
+                ("num_dims", C.c_int32), ("num_residuals", C.c_int32)]
 
 
 HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double), i64p)

@@ -53,15 +53,17 @@ def distributed_scipy_solver(asm, plan, dist):
     gid = plan.node_gid
     N = plan.part.num_global_nodes
     world = plan.world
+    NEQ = asm.neq                    # (3, 1), or (2, 1) on tri3 meshes
+    nres = getattr(asm, "nres", 2)   # 1 under mechanics_plane_stress: the u block alone
 
     def solve(user, sys_p, dx_p):
         sys = sys_p.contents
         mine = {"b": [], "A": {}}
-        for i in range(2):
+        for i in range(nres):
             nrows = no * NEQ[i]
             mine["b"].append((np.repeat(gid[:no], NEQ[i]) * NEQ[i] + np.tile(np.arange(NEQ[i]), no),
                               _DevView(sys.b[i], n * NEQ[i], asm.device).to_numpy()[:nrows]))
-            for j in range(2):
+            for j in range(nres):
                 vals = _DevView(sys.A[i][j], nnz[i][j], asm.device).to_numpy()[: rp[i][j][nrows]]
                 cols = ci[i][j][: rp[i][j][nrows]]
                 gcol = gid[cols // NEQ[j]] * NEQ[j] + cols % NEQ[j]
@@ -72,20 +74,20 @@ def distributed_scipy_solver(asm, plan, dist):
             dist.all_gather_object(allp, mine)
         else:
             allp = [mine]
-        blocks = [[None, None], [None, None]]
-        for i in range(2):
-            for j in range(2):
+        blocks = [[None] * nres for _ in range(nres)]
+        for i in range(nres):
+            for j in range(nres):
                 r = np.concatenate([q["A"][(i, j)][0] for q in allp])
                 c = np.concatenate([q["A"][(i, j)][1] for q in allp])
                 v = np.concatenate([q["A"][(i, j)][2] for q in allp])
                 blocks[i][j] = sp.csr_matrix((v, (r, c)), shape=(N * NEQ[i], N * NEQ[j]))
-        b = [np.zeros(N * NEQ[i]) for i in range(2)]
+        b = [np.zeros(N * NEQ[i]) for i in range(nres)]
         for q in allp:
-            for i in range(2):
+            for i in range(nres):
                 b[i][q["b"][i][0]] = q["b"][i][1]
         x = spla.spsolve(sp.bmat(blocks, format="csc"), np.concatenate(b))
-        xs = [x[: N * 3], x[N * 3:]]
-        for i in range(2):
+        xs = [x[: N * NEQ[0]], x[N * NEQ[0]:]]
+        for i in range(nres):
             loc = np.zeros(n * NEQ[i])
             loc[: no * NEQ[i]] = xs[i][mine["b"][i][0]]
             _DevView(dx_p[i], n * NEQ[i], asm.device).from_numpy(loc)

@@ -346,6 +346,9 @@ typedef struct {
   const int32_t* import_nodes;
   const int64_t* export_ptr;        /* [nranks+1] */
   const int32_t* export_nodes;
+  /* shape of the systems the tables are for: equations per node of residual 0 (c8_num_dims: 3, or 2 on tri3 meshes) and
+   * the number of residuals (c8_num_residuals: 2, or 1 under mechanics_plane_stress); 0 = 3 and 2 */
+  int32_t num_dims, num_residuals;
 } c8_halo_desc;
 /* Index tables of the exchanges, built on the host from the part's node graph (= block (1,1) of c8_graph(): one row
  * per node, sorted neighbour ids) -- needs no device. */
@@ -365,7 +368,8 @@ enum { C8_HALO_B = 1, C8_HALO_A = 2 };
 int c8_halo_gather_start(c8_halo* halo, const c8_system* sys, int what);
 int c8_halo_gather_finish(c8_halo* halo, const c8_system* sys);
 int c8_halo_gather(c8_halo* halo, const c8_system* sys, int what);
-/* C3: owner values of a nodal field pair x = {u [nodes*3], p [nodes]} copied to every ghost and phantom copy. */
+/* C3: owner values of a nodal field pair x = {u [nodes*num_dims], p [nodes]} (x[1] unused with one residual) copied to
+ * every ghost and phantom copy. */
 int c8_halo_scatter_x(c8_halo* halo, double* const x[2]);
 /* bytes this rank sends per exchange (what = C8_HALO_A | C8_HALO_B, or 0 for the C3 import) */
 int64_t c8_halo_send_bytes(const c8_halo* halo, int what);

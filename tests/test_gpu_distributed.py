@@ -324,6 +324,76 @@ def test_step_drivers_over_two_parts_reproduce_the_single_part_run():
         assert np.abs(res["grad"] - res["ref_grad"]).max() < 1e-7 * np.abs(res["ref_grad"]).max(), (r, res["grad"], res["ref_grad"])
 
 
+# ---- 2-D meshes over parts: 2 + 1 equations per node (`mechanics` on tri3) and 2 (`mechanics_plane_stress`) -------------
+def driver_worker_2d(rank, world, port, out, model, params):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from calibr8_amd import Assembler
+        from calibr8_amd import distributed as D
+        from calibr8_amd.primal import PrimalDriver, adjoint_gradient, distributed_scipy_solver
+        from meshes import jiggle_2d, tri_mesh
+        c, conn, sets = tri_mesh(8, 6, 1.0, 0.8)
+        c = jiggle_2d(c, sets, 0.02)
+        ep = (c[conn].mean(axis=1)[:, 0] > 0.47).astype(np.int32) if world == 2 else np.zeros(len(conn), dtype=np.int32)
+        part = D.part_from_global(c, conn, ep, rank, world)
+        plan = D.HaloPlan(part, dist)
+        asm = Assembler(3, c[plan.node_gid], part.conn, model, params, extra_pairs=plan.extra_pairs)
+        comm = D.Comm.host(dist, rank, world)
+        halo = D.Halo(plan, asm.rowptr[1][1], asm.colidx[1][1], asm, comm)  # the tables take the assembler's ndims / nres
+        gid, no = plan.node_gid, part.nowned
+        lc = c[gid]
+        lo, hi = c.min(axis=0), c.max(axis=0)
+
+        def bcs(coords):
+            of = lambda ax, v: np.nonzero(np.abs(coords[:, ax] - v) < 1e-9)[0].astype(np.int32)
+            return [(0, 0, of(0, lo[0]), lambda x, y, z, t: 0.0), (0, 1, of(1, lo[1]), lambda x, y, z, t: 0.0),
+                    (0, 1, of(1, hi[1]), lambda x, y, z, t: 0.002 * t)]
+
+        act = [0, 1, 2, 3]
+        asm.set_active(0, act)
+        drv = PrimalDriver(asm, bcs(lc), max_iters=30, solver=distributed_scipy_solver(asm, plan, dist))
+        drv.solve(2)
+        J = comm.allreduce(np.array([drv.qoi()]))[0]
+        grad = comm.allreduce(adjoint_gradient(drv, len(act)))
+        res = {"iters": list(drv.newton_iters), "J": float(J), "grad": grad, "nres": asm.nres,
+               "send_bytes": halo.send_bytes(3), "import_bytes": halo.send_bytes(0), "nghost": part.ntouched - no}
+        ref = Assembler(3, c, conn, model, params)
+        ref.set_active(0, act)
+        rdrv = PrimalDriver(ref, bcs(c), max_iters=30)
+        rdrv.solve(2)
+        res["ref_iters"], res["ref_J"], res["ref_grad"] = list(rdrv.newton_iters), rdrv.qoi(), adjoint_gradient(rdrv, len(act))
+        torch.cuda.synchronize()
+        ug = rdrv.u[2].cpu().numpy().reshape(-1, 2)[gid].ravel()
+        res["du"] = float(np.abs(drv.u[2].cpu().numpy() - ug).max() / np.abs(ug).max())
+        res["dxi"] = float((drv.xi[2].cpu() - rdrv.xi[2].cpu()[np.nonzero(ep == rank)[0]]).abs().max())
+        res["alpha"] = float(rdrv.xi[2][:, :, 3].max())
+        halo.close()
+        comm.close()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["small_J2", "small_hill_plane_stress"])
+def test_step_drivers_over_two_parts_on_2d_meshes(model):
+    # the halo tables for 2 + 1 equations per node (tri3 under `mechanics`) and for one residual with 2 equations
+    # (`mechanics_plane_stress`): c8_halo_desc.num_dims / num_residuals; both step drivers over two parts reproduce the
+    # single-part run
+    params = J2 if model == "small_J2" else [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.1, 0.9, 1.05]
+    out = spawn(driver_worker_2d, 2, model, params)
+    for r in range(2):
+        res = out[r]
+        assert res["nres"] == (2 if model == "small_J2" else 1)
+        assert res["iters"] == res["ref_iters"] and max(res["iters"]) > 2 and res["alpha"] > 1e-4, (r, res)
+        assert res["du"] < 1e-9 and res["dxi"] < 1e-9, (r, res["du"], res["dxi"])
+        assert abs(res["J"] - res["ref_J"]) < 1e-9 * abs(res["ref_J"]), (r, res["J"], res["ref_J"])
+        assert np.abs(res["grad"] - res["ref_grad"]).max() < 1e-7 * np.abs(res["ref_grad"]).max(), (r, res["grad"], res["ref_grad"])
+    # a node travels with 3 (u_x, u_y, p) or 2 values in the import exchange
+    per_node = 3 if model == "small_J2" else 2
+    assert sum(out[r]["import_bytes"] for r in range(2)) % (8 * per_node) == 0 and sum(out[r]["send_bytes"] for r in range(2)) > 0
+
+
 # ---- the calibration objective over two parts (through the halo's communicator) ---------------------------------------
 def evaluate(asm, c, conn, u, p, xi_prev, z_u, z_p, u_meas):
     """objective value and parameter gradient of one (part of a) mesh at a prescribed state"""
@@ -435,7 +505,7 @@ def test_rccl_transport_single_rank_self_exchange():
     plan.recv_cols = np.concatenate([ci[rp[n]:rp[n + 1]] for n in send_nodes])
     plan.import_ptr, plan.import_nodes = np.array([0, nsend]), send_nodes
     plan.export_ptr, plan.export_nodes = np.array([0, nsend]), recv_nodes
-    plan.desc = lambda: D.HaloPlan.desc(plan)
+    plan.desc = lambda ndims=3, nres=2: D.HaloPlan.desc(plan, ndims, nres)
     comm = D.Comm.rccl(None, 0, 1)
     v = comm.allreduce(np.array([1.5, -2.0, 3.25]))
     assert np.array_equal(v, [1.5, -2.0, 3.25])
