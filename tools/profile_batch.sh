@@ -1,5 +1,5 @@
 #!/bin/bash
-# closing profile batch of a round (runs on the GPU box from the repo root)
+# closing profile batch of a round (runs on the GPU box from the repo root): tools/profile_batch.sh <tag> [<profiles prefix>]
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-batch}
@@ -8,14 +8,17 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 echo prof_atomic done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gather -- python3 bench.py --no-cpu --scatter gather > $O/prof_gather.log 2>&1 || exit 1
 echo prof_gather done
+timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_atomic.json -- --scatter atomic > $O/pmc_atomic.log 2>&1 || exit 1
+timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_gather.json -- --scatter gather > $O/pmc_gather.log 2>&1 || exit 1
+echo pmc done
+# the bench line takes roofline.traffic / roofline.valu from a PMC profile of THIS build under profiles/: put the one just
+# collected there (on the box; tools/save_profiles.py does the same in the repository) before the bench runs
+if [ -n "$2" ]; then cp $O/pmc_gather.json profiles/$2_traffic_wave_gather_100cube.json; fi
 timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo bench default done
 timeout -k 10 200 python3 bench.py --no-cpu --scatter atomic > $O/bench_atomic.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scatter colored > $O/bench_colored.json 2>/dev/null || exit 1
 echo bench modes done
-timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_atomic.json -- --scatter atomic > $O/pmc_atomic.log 2>&1 || exit 1
-timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_gather.json -- --scatter gather > $O/pmc_gather.log 2>&1 || exit 1
-echo pmc done
 timeout -k 10 300 python3 tools/bench_kernels.py > $O/kernels_small_J2.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model hyper_J2 > $O/kernels_hyper_J2.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model small_hill > $O/kernels_small_hill.json 2>/dev/null || exit 1
