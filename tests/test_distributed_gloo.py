@@ -157,6 +157,76 @@ def test_eight_analytic_brick_parts_gloo():
     run(8, (4, 4, 4), (2, 2, 2), use_brick_part=True)
 
 
+def worker_2d(rank, world, port, model, params, out):
+    """tri3 parts: the exchange tables for 2 + 1 equations per node (`mechanics`) and for ONE residual with 2 equations
+    (`mechanics_plane_stress`), c8_halo_desc.num_dims / num_residuals"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as ol
+        from calibr8_amd import distributed as D
+        from halo_replay import HaloReplay
+        from meshes import fields_for, jiggle_2d, prescribed_fields, tri_mesh
+        c, conn, sets = tri_mesh(9, 6, 1.0, 0.8)
+        c = jiggle_2d(c, sets, 0.02)
+        u, p = fields_for(2, *prescribed_fields(c, 0.004, ramp=True, perturb=5e-2))
+        ep = np.minimum((c[conn].mean(axis=1)[:, 0] * world).astype(np.int32), world - 1)  # vertical strips
+        part = D.part_from_global(c, conn, ep, rank, world)
+        plan = D.HaloPlan(part, dist)
+        gid, no = plan.node_gid, part.nowned
+        orc = ol.Oracle(ol.TRI3, c[gid], part.conn, model, params, extra_pairs=plan.extra_pairs)
+        nres, neq = orc.nres, (2, 1)
+        halo = D.Halo(plan, orc.rowptr[1][1], orc.colidx[1][1], ndims=2, nres=nres)
+        rep = HaloReplay(halo, dist, world)
+        lu, lp = np.ascontiguousarray(u.reshape(-1, 2)[gid].ravel()), np.ascontiguousarray(p[gid])
+        ls, xi = orc.new_linsys(), orc.new_state()
+        assert orc.forward_jacobian(lu, lp, 0 * lu, 0 * lp, orc.new_state(), xi, ls) == 0
+        blocks = [(i, j) for i in range(2) for j in range(2)]
+        segs = [ls.A[i][j] if max(i, j) < nres else None for i, j in blocks] + [ls.b[i] if i < nres else None for i in range(2)]
+        rep.gather(segs)
+        ref = ol.Oracle(ol.TRI3, c, conn, model, params)
+        lr = ref.new_linsys()
+        assert ref.forward_jacobian(u, p, 0 * u, 0 * p, ref.new_state(), ref.new_state(), lr) == 0
+        worst = 0.0
+        for i in range(nres):
+            bo = ls.b[i][: no * neq[i]].reshape(no, neq[i])
+            worst = max(worst, np.abs(bo - lr.b[i].reshape(-1, neq[i])[gid[:no]]).max() / np.abs(lr.b[i]).max())
+            grow = np.repeat(gid[:no], neq[i]) * neq[i] + np.tile(np.arange(neq[i]), no)
+            for j in range(nres):
+                Ag = sp.csr_matrix((lr.A[i][j], ref.colidx[i][j], ref.rowptr[i][j]), shape=(len(c) * neq[i], len(c) * neq[j]))
+                rp, ci = orc.rowptr[i][j], orc.colidx[i][j]
+                nrows = no * neq[i]
+                cols_l = ci[: rp[nrows]]
+                gcol = gid[cols_l // neq[j]] * neq[j] + cols_l % neq[j]
+                Al = sp.csr_matrix((ls.A[i][j][: rp[nrows]], gcol, rp[: nrows + 1]), shape=(nrows, len(c) * neq[j]))
+                worst = max(worst, abs(Al - Ag[grow]).max() / abs(Ag).max())
+        x = [lu.copy(), lp.copy() if nres == 2 else None]
+        x[0][no * 2:] = -7.0
+        if nres == 2:
+            x[1][no:] = -7.0
+        rep.scatter_x(x)
+        ok_x = np.array_equal(x[0], lu) and (nres == 1 or np.array_equal(x[1], lp))
+        per_node = 2 + (1 if nres == 2 else 0)
+        ok_n = int(halo.table(21).sum()) == per_node * int(np.diff(plan.export_ptr).sum())  # values sent by the C3 import
+        out[rank] = (worst, ok_x, ok_n, nres, len(plan.phantom_gid))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,world", [("small_J2", 2), ("small_hill_plane_stress", 3)])
+def test_2d_parts_gloo(model, world):
+    params = J2 if model == "small_J2" else [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.1, 0.9, 1.05]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(worker_2d, args=(world, free_port(), model, params, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        worst, ok_x, ok_n, nres, nph = out[r]
+        assert nres == (2 if model == "small_J2" else 1)
+        assert worst < 1e-13 and ok_x and ok_n, (r, worst, ok_x, ok_n)
+    assert sum(out[r][4] for r in range(world)) > 0
+
+
 def adjoint_worker(rank, world, port, n, pdims, out):
     """K3 -> C2/C1, C3, K4, K5 -> C4 on every part (SURVEY 8e 'adjoint specifics'): the histories g, f stay local,
     z needs the owner -> ghost copy before K4/K5, the gradient is one packed all-reduce."""
