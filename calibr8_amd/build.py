@@ -6,7 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libc8.so")
-SOURCES = ["c8_kernels.hip", "c8_api.hip", "c8_primal.hip", "c8_qoi.hip", "c8_halo.hip", "c8_host.cpp", "c8_lbfgs.cpp"]
+KERNEL_PARTS = 6  # c8_kernels.hip is compiled once per group of template instantiations (-DC8_KERNEL_PART=n), in parallel
+SOURCES = ["c8_kernels.hip:%d" % k for k in range(KERNEL_PARTS)] + ["c8_api.hip", "c8_primal.hip", "c8_qoi.hip", "c8_halo.hip",
+                                                                      "c8_host.cpp", "c8_lbfgs.cpp"]
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
@@ -65,20 +67,31 @@ def build(force=False, verbose=False):
     flags_same = old[0] == flags_now
     headers = [p for p in _inputs() if p.endswith((".hpp", ".h"))]
     newest_header = max(os.path.getmtime(h) for h in headers)
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    objs, jobs = [], []
+    for entry in SOURCES:
+        src, _, part = entry.partition(":")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ("_p" + part if part else "") + ".o")
         srcp = os.path.join(CSRC, src)
         fresh = flags_same and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), newest_header)
         if src == "c8_api.hip":  # carries the build id
             fresh = fresh and len(old) > 1 and old[1] == bid
         if force or not fresh:
             extra = ['-DC8_BUILD_ID="%s"' % bid, '-DC8_BUILD_FLAGS="%s"' % flags_now] if src == "c8_api.hip" else []
-            cmd = [hipcc] + fl + extra + ["-x", "hip", "-c", srcp, "-o", obj]
+            if part:
+                extra.append("-DC8_KERNEL_PART=" + part)
+            jobs.append([hipcc] + fl + extra + ["-x", "hip", "-c", srcp, "-o", obj])
+        objs.append(obj)
+    if jobs:  # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-        objs.append(obj)
+
+        workers = max(1, min(len(jobs), int(os.environ.get("C8_BUILD_JOBS", "0")) or (os.cpu_count() or 4)))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(run, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))

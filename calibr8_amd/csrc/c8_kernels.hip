@@ -501,8 +501,50 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   return ks;
 }
 
-// the registry: one line per constitutive model (local_residual.cpp:893-933)
-template <class E> static KernelSet kernel_set_for(int model) {
+// The registry: one line per constitutive model (local_residual.cpp:893-933).  The instantiations are compiled in
+// PARTS -- this file is compiled once per part with -DC8_KERNEL_PART=n (calibr8_amd/build.py, in parallel) and once as a
+// whole by the tools that read its assembly; every part is a function the registry of part 0 dispatches to.
+#ifndef C8_KERNEL_PART
+#define C8_KERNEL_PART -1  // all parts in this translation unit
+#endif
+#define C8_PART(n) (C8_KERNEL_PART == -1 || C8_KERNEL_PART == (n))
+KernelSet kernels_hex8_a(int model);       // part 0: elastic, small_J2, isotropic_elastic (+ get_kernels)
+KernelSet kernels_hex8_b(int model);       // part 1: hyper_J2, small_hill
+KernelSet kernels_hex8_c(int model);       // part 2: hypo_hill
+KernelSet kernels_tet4(int model);         // part 3: the six models on tet4
+KernelSet kernels_2d(int model);           // part 4: tri3 under mechanics and mechanics_plane_stress
+KernelSet kernels_line_search(int elem_type, int model);  // part 5: Hosford / Barlat on tet4 and hex8
+
+#if C8_PART(0)
+KernelSet kernels_hex8_a(int model) {
+  using E = Elem<C8_HEX8>;
+  switch (model) {
+    case MODEL_ELASTIC: return kernel_set<E, Elastic>();
+    case MODEL_SMALL_J2: return kernel_set<E, SmallJ2>();
+    case MODEL_ISOTROPIC_ELASTIC: return kernel_set<E, IsotropicElastic>();
+  }
+  return KernelSet{};
+}
+#endif
+#if C8_PART(1)
+KernelSet kernels_hex8_b(int model) {
+  using E = Elem<C8_HEX8>;
+  switch (model) {
+    case MODEL_HYPER_J2: return kernel_set<E, HyperJ2>();
+    case MODEL_SMALL_HILL: return kernel_set<E, SmallHill>();
+  }
+  return KernelSet{};
+}
+#endif
+#if C8_PART(2)
+KernelSet kernels_hex8_c(int model) {
+  if (model == MODEL_HYPO_HILL) return kernel_set<Elem<C8_HEX8>, HypoHill>();
+  return KernelSet{};
+}
+#endif
+#if C8_PART(3)
+KernelSet kernels_tet4(int model) {
+  using E = Elem<C8_TET4>;
   switch (model) {
     case MODEL_ELASTIC: return kernel_set<E, Elastic>();
     case MODEL_SMALL_J2: return kernel_set<E, SmallJ2>();
@@ -510,34 +552,52 @@ template <class E> static KernelSet kernel_set_for(int model) {
     case MODEL_SMALL_HILL: return kernel_set<E, SmallHill>();
     case MODEL_ISOTROPIC_ELASTIC: return kernel_set<E, IsotropicElastic>();
     case MODEL_HYPO_HILL: return kernel_set<E, HypoHill>();
-    case MODEL_SMALL_HOSFORD: return kernel_set<E, SmallHosford>();
-    case MODEL_HYPO_HOSFORD: return kernel_set<E, HypoHosford>();
-    case MODEL_HYPO_BARLAT: return kernel_set<E, HypoBarlat>();
   }
   return KernelSet{};
 }
-
-// 2-D meshes: the models the reference's 2-D decks run on `mechanics` with 2 + 1 equations per node
-static KernelSet kernel_set_2d(int model) {
+#endif
+#if C8_PART(4)
+// 2-D meshes: the models the reference's 2-D decks run on `mechanics` with 2 + 1 equations per node ...
+KernelSet kernels_2d(int model) {
   switch (model) {
     case MODEL_SMALL_J2: return kernel_set<Elem<C8_TRI3>, SmallJ2Plane>();
     case MODEL_SMALL_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, SmallHillPlaneStrain>();
     case MODEL_HYPER_J2_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, HyperJ2PlaneStrain>();
     case MODEL_HYPO_HILL_PLANE_STRAIN: return kernel_set<Elem<C8_TRI3>, HypoHillPlaneStrain>();
-    // `mechanics_plane_stress`: one residual, six element DOFs
+    // ... and `mechanics_plane_stress`: one residual, six element DOFs
     case MODEL_SMALL_HILL_PLANE_STRESS: return kernel_set<Tri3PlaneStress, SmallHillPlaneStress>();
     case MODEL_HYPER_J2_PLANE_STRESS: return kernel_set<Tri3PlaneStress, HyperJ2PlaneStress>();
     case MODEL_HYPO_HILL_PLANE_STRESS: return kernel_set<Tri3PlaneStress, HypoHillPlaneStress>();
   }
   return KernelSet{};
 }
-
-KernelSet get_kernels(int elem_type, int model) {
-  if (elem_type == C8_TRI3) return kernel_set_2d(model);
-  if (model >= MODEL_SMALL_HILL_PLANE_STRAIN && model <= MODEL_HYPO_HILL_PLANE_STRESS) return KernelSet{};  // the plane models exist on 2-D meshes only
-  if (elem_type == C8_HEX8) return kernel_set_for<Elem<C8_HEX8>>(model);
-  if (elem_type == C8_TET4) return kernel_set_for<Elem<C8_TET4>>(model);
+#endif
+#if C8_PART(5)
+template <class E> static KernelSet line_search_set(int model) {
+  switch (model) {
+    case MODEL_SMALL_HOSFORD: return kernel_set<E, SmallHosford>();
+    case MODEL_HYPO_HOSFORD: return kernel_set<E, HypoHosford>();
+    case MODEL_HYPO_BARLAT: return kernel_set<E, HypoBarlat>();
+  }
   return KernelSet{};
 }
+KernelSet kernels_line_search(int elem_type, int model) {
+  return elem_type == C8_HEX8 ? line_search_set<Elem<C8_HEX8>>(model) : line_search_set<Elem<C8_TET4>>(model);
+}
+#endif
+
+#if C8_PART(0)
+KernelSet get_kernels(int elem_type, int model) {
+  if (elem_type == C8_TRI3) return kernels_2d(model);
+  if (model >= MODEL_SMALL_HILL_PLANE_STRAIN && model <= MODEL_HYPO_HILL_PLANE_STRESS) return KernelSet{};  // the plane models exist on 2-D meshes only
+  if (elem_type != C8_HEX8 && elem_type != C8_TET4) return KernelSet{};
+  if (model >= MODEL_SMALL_HOSFORD) return kernels_line_search(elem_type, model);
+  if (elem_type == C8_TET4) return kernels_tet4(model);
+  KernelSet ks = kernels_hex8_a(model);
+  if (!ks.forward_jacobian) ks = kernels_hex8_b(model);
+  if (!ks.forward_jacobian) ks = kernels_hex8_c(model);
+  return ks;
+}
+#endif
 
 }  // namespace c8
