@@ -281,7 +281,9 @@ class Assembler:
                             coord_tol=1e-8, comp=1, dt_over_T=1.0):
         """Calibration objective (calibration.cpp): faces = node ids of the displacement side set [n][3|4] (host),
         load plane = nodes with |x[coord_idx] - coord_value| < coord_tol, reaction component comp."""
-        f = np.ascontiguousarray(faces, dtype=np.int32)
+        f = np.ascontiguousarray(faces if faces is not None and len(faces) else np.zeros((0, 1)), dtype=np.int32)
+        if f.ndim == 1:  # tri3 meshes: element ids of the displacement term (none = every element)
+            f = f.reshape(-1, 1)
         d = _l.CalibrationDesc()
         d.num_faces, d.nodes_per_face, d.faces = f.shape[0], f.shape[1], f.ctypes.data
         for k in range(3):

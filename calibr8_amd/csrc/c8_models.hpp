@@ -667,6 +667,7 @@ template <class T> struct HillPlane {
 
 // ---- small_hill_plane_stress.cpp: small strain, eps_zz eliminated by sigma_zz = 0 (:318-329) ----------------------------
 template <class T> struct SmallHillPlaneStress {
+  static constexpr bool PLANE_STRESS = true;  // pairs with mechanics_plane_stress (one global residual)
   static constexpr int NLOC = 4, NPARAMS = 9;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
@@ -726,6 +727,7 @@ template <class T> struct SmallHillPlaneStress {
 // ---- hyper_J2_plane_stress.cpp: finite-deformation J2; local unknowns zeta (00,01,11), Ie, the out-of-plane stretch
 //      lambda_z and alpha.  F_3D = [F_2D, lambda_z], zeta_zz = -tr(zeta); lambda_z closes sigma_zz = 0 (:302-304) --------
 template <class T> struct HyperJ2PlaneStress {
+  static constexpr bool PLANE_STRESS = true;  // pairs with mechanics_plane_stress (one global residual)
   static constexpr int NLOC = 6, NPARAMS = 8;
   static constexpr int Z_STRETCH = 4;  // m_z_stretch_idx (:60): position of lambda_z in xi
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
@@ -830,6 +832,7 @@ template <class T> struct HyperJ2PlaneStress {
 //      out-of-plane stretch lambda_z; the material axes Q rotate the rate of deformation (:164-177) and the stress
 //      (:378-388).  The TC rows of the plastic residual are divided by val(mu) on the unforced path only (:303). ---------
 template <class T> struct HypoHillPlaneStress {
+  static constexpr bool PLANE_STRESS = true;  // pairs with mechanics_plane_stress (one global residual)
   static constexpr int NLOC = 5, NPARAMS = 13;
   static constexpr int Z_STRETCH = 4;  // m_z_stretch_idx (:72)
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
@@ -1365,13 +1368,23 @@ struct QoiArgs {
   int comp;
   double const* S;  // [nelems][coupled points][3], null when c_load == 0
   double ndims = 3.;  // "average displacement" divides by the number of dimensions (avg_disp.cpp:27)
+  double thickness = 1.;  // mechanics_plane_stress: the internal force of the load term carries it (mechanics_plane_stress.cpp:90)
 };
+template <class L, class = void> struct is_plane_stress : std::false_type {};
+template <class L> struct is_plane_stress<L, std::enable_if_t<L::PLANE_STRESS>> : std::true_type {};
 struct PointQoi {
   template <class T, class Local>
   C8_HD static T evaluate(PointState<T> const& g, Local const& local, double wdv, QoiArgs const& qa, size_t qp) {
     T v = (g.u[0] + g.u[1] + g.u[2]) * (qa.c_avg * wdv / qa.ndims);
     if (qa.c_load != 0.) {  // uniform over the launch
-      Tens3<T> const Gu = Mechanics::flux_u(local, g);
+      Tens3<T> Gu;  // the displacement flux of the element's global residual (compute_load re-enters it, calibration.cpp:334)
+      if constexpr (is_plane_stress<Local>::value) {
+        MechFlux<T> f;
+        MechanicsPlaneStress::flux(local, g, qa.thickness, f);
+        Gu = f.Gu;
+      } else {
+        Gu = Mechanics::flux_u(local, g);
+      }
       double const s0 = qa.S[qp * 3] * (qa.c_load * wdv), s1 = qa.S[qp * 3 + 1] * (qa.c_load * wdv),
                    s2 = qa.S[qp * 3 + 2] * (qa.c_load * wdv);
       T const r0 = Gu.xx * s0 + Gu.xy * s1 + Gu.xz * s2;

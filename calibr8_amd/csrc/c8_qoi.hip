@@ -34,17 +34,17 @@ namespace {
 // J (if not null) += value; b0 (if not null) -= d value / d u   (the adjoint right-hand side is -dJ/dx).
 __global__ void k_surface_mismatch(int n, int nf, int32_t const* face_nodes, double const* coords, double const* u,
                                    double const* u_meas, double w0, double w1, double w2, double scale, double* J,
-                                   double* b0) {
+                                   double* b0, int ndims) {
   int const f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n) return;
   int32_t const* fn = face_nodes + (size_t)f * 4;
   double const wt[3] = {w0, w1, w2};
   double grad[4][3];
-  double const val = surface_mismatch_face(nf, fn, coords, u, u_meas, wt, grad);
+  double const val = surface_mismatch_face(nf, fn, coords, u, u_meas, wt, grad, ndims);
   if (J) unsafeAtomicAdd(J, val * scale);
   if (b0)
     for (int k = 0; k < nf; ++k)
-      for (int d = 0; d < 3; ++d) unsafeAtomicAdd(&b0[(size_t)fn[k] * 3 + d], -(grad[k][d] * scale));
+      for (int d = 0; d < ndims; ++d) unsafeAtomicAdd(&b0[(size_t)fn[k] * ndims + d], -(grad[k][d] * scale));
 }
 
 __global__ void k_add_scalar(double* x, double v) { *x += v; }
@@ -55,7 +55,7 @@ __global__ void k_add_scalar(double* x, double v) { *x += v; }
 // the point integrand of the adjoint kernels (K3, K5): x, xi or parameter derivatives of the objective
 QoiArgs c8_qoi_args(c8_ctx const* c) {
   if (c->qoi_kind == 0) return QoiArgs{1., 0., 0, nullptr, (double)c->ndims};
-  return QoiArgs{0., c->cal_balance * c->cal_dt_over_T * c->cal_load_mismatch, c->cal_comp, c->d_cal_S};
+  return QoiArgs{0., c->cal_balance * c->cal_dt_over_T * c->cal_load_mismatch, c->cal_comp, c->d_cal_S, (double)c->ndims, c->ms.thickness};
 }
 
 // preprocess_qoi: the total reaction load of the step and its mismatch with the measured load
@@ -63,7 +63,7 @@ int c8_qoi_prepare(c8_ctx* c, FieldArgs const& fa) {
   if (c->qoi_kind == 0) return C8_OK;
   if (!c->d_u_meas) return c8_fail(C8_ERR_ARG, "calibration objective: c8_set_measured has not been called");
   QH(hipMemsetAsync(c->d_scalar, 0, sizeof(double), c->stream));
-  AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, c->d_scalar, c->d_active, QoiArgs{0., 1., c->cal_comp, c->d_cal_S}};
+  AdjointArgs aa{nullptr, nullptr, nullptr, nullptr, nullptr, c->d_scalar, c->d_active, QoiArgs{0., 1., c->cal_comp, c->d_cal_S, (double)c->ndims, c->ms.thickness}};
   MeshTables mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params};
   LaunchArgs a{mt, c->ms, fa, aa, SystemArgs{}, 0, c->mesh.nelems, c->stream};
   QH(c->ks.qoi(a));
@@ -86,7 +86,7 @@ int c8_qoi_surface(c8_ctx* c, double const* u, double* J, double* b0) {
   double const scale = (double)c->npts0 * c->cal_dt_over_T / c->cal_area;
   int const n = c->cal_nfaces;
   hipLaunchKernelGGL(k_surface_mismatch, dim3((n + 127) / 128), dim3(128), 0, c->stream, n, c->cal_nf, c->d_cal_faces,
-                     c->d_coords, u, c->d_u_meas, c->cal_w[0], c->cal_w[1], c->cal_w[2], scale, J, b0);
+                     c->d_coords, u, c->d_u_meas, c->cal_w[0], c->cal_w[1], c->cal_w[2], scale, J, b0, c->ndims);
   QH(hipGetLastError());
   return C8_OK;
 }
@@ -111,16 +111,20 @@ int c8_set_qoi_avg_disp(c8_ctx* c) {
 
 int c8_set_qoi_calibration(c8_ctx* c, const c8_calibration_desc* d) {
   if (!c || !d || d->num_faces < 0 || (d->num_faces > 0 && !d->faces)) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: bad argument");
-  if (c->ndims != 3) return c8_fail(C8_ERR_UNSUPPORTED, "c8_set_qoi_calibration: the calibration objective is built in its 3-D form (calibration.cpp:32-34 is the 2-D branch)");
-  int const nn = c->mesh.nn, nfn = (nn == 4) ? 3 : 4, nfe = (nn == 4) ? 4 : 6;
-  if (d->num_faces > 0 && d->nodes_per_face != nfn) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: faces must have 3 nodes (tet4) or 4 (hex8)");
-  if (d->coord_idx < 0 || d->coord_idx > 2 || d->reaction_comp < 0 || d->reaction_comp > 2) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: coordinate index / component out of range");
+  int const nn = c->mesh.nn, nfn = (nn == 8) ? 4 : 3;
+  // 3-D: faces of the displacement side set; 2-D (calibration.cpp:76-104): every element, or the listed element ids
+  if (d->num_faces > 0 && d->nodes_per_face != (nn == 3 ? 1 : nfn))
+    return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: faces must have 3 nodes (tet4) or 4 (hex8); on a tri3 mesh the list holds element ids (nodes_per_face = 1)");
+  if (nn == 3)
+    for (int f = 0; f < d->num_faces; ++f)
+      if (d->faces[f] < 0 || d->faces[f] >= c->mesh.nelems) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: element id out of range");
+  if (d->coord_idx < 0 || d->coord_idx >= c->ndims || d->reaction_comp < 0 || d->reaction_comp >= c->ndims) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: coordinate index / component out of range");
   CalibrationTables t;
   calibration_tables(c->mesh, d->num_faces, d->faces, d->coord_idx, d->coord_value, d->coord_tol, t);
   std::vector<int32_t> const& faces = t.faces;
   std::vector<double> const& S = t.S;
   double const area = t.area;
-  if (d->num_faces > 0 && !(area > 0.) && !c->allreduce && !c->halo) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
+  if ((d->num_faces > 0 || nn == 3) && !(area > 0.) && !c->allreduce && !c->halo) return c8_fail(C8_ERR_ARG, "c8_set_qoi_calibration: no element face lies on the displacement side set");
   (void)hipFree(c->d_cal_faces);
   (void)hipFree(c->d_cal_S);
   c->d_cal_faces = nullptr;
@@ -160,7 +164,7 @@ int c8_set_measured(c8_ctx* c, const double* u_meas, double load_meas) {
 }
 
 int c8_qoi_preprocess(c8_ctx* c, const c8_state* st, double* out) {
-  if (!c || !st || !st->x[0] || !st->x[1] || !st->xi || !st->xi_prev) return c8_fail(C8_ERR_ARG, "c8_qoi_preprocess: null argument");
+  if (!c || !st || !st->x[0] || (c->nres == 2 && !st->x[1]) || !st->xi || !st->xi_prev) return c8_fail(C8_ERR_ARG, "c8_qoi_preprocess: null argument");
   FieldArgs fa{st->x[0], st->x[1], st->x_prev[0], st->x_prev[1], st->xi_prev, st->xi};
   int const rc = c8_qoi_prepare(c, fa);
   if (rc) return rc;

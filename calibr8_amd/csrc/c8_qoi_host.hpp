@@ -72,19 +72,21 @@ inline double face_area(int nf, double const X[][3]) {
 // shape functions reduce to the face's own, so the interpolation of the element field at boundaryToElementXi(point)
 // is the face interpolation of the nodal values.  Returns the unscaled value 1/2 sum_q sum_d w_d (u_d - u_meas_d)^2
 // w dv and its derivative with respect to the nodal displacements of the face.
+// With ndims = 2 the "face" is a tri3 ELEMENT of a 2-D mesh and the same integral is compute_disp_mismatch
+// (calibration.cpp:163-222): its order-2 rule is the three-point rule of the triangle.
 C8_HD double surface_mismatch_face(int nf, int32_t const* fn, double const* coords, double const* u, double const* u_meas,
-                                   double const* wt, double grad[4][3]) {
+                                   double const* wt, double grad[4][3], int ndims = 3) {
   double X[4][3], Nf[4][4], wdv[4], du[4][3];
   for (int k = 0; k < nf; ++k)
     for (int d = 0; d < 3; ++d) {
       X[k][d] = coords[(size_t)fn[k] * 3 + d];
-      du[k][d] = u[(size_t)fn[k] * 3 + d] - u_meas[(size_t)fn[k] * 3 + d];
+      du[k][d] = d < ndims ? u[(size_t)fn[k] * ndims + d] - u_meas[(size_t)fn[k] * ndims + d] : 0.;
       grad[k][d] = 0.;
     }
   int const nq = face_rule(nf, X, Nf, wdv);
   double val = 0.;
   for (int q = 0; q < nq; ++q)
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < ndims; ++d) {
       double diff = 0.;
       for (int k = 0; k < nf; ++k) diff += du[k][d] * Nf[q][k];
       val += 0.5 * wt[d] * diff * diff * wdv[q];
@@ -121,6 +123,30 @@ struct CalibrationTables {
 };
 inline void calibration_tables(HostMesh const& mesh, int num_faces, int32_t const* side_faces, int coord_idx, double coord_value,
                                double coord_tol, CalibrationTables& t) {
+  if (mesh.nn == 3) {
+    // 2-D branch (calibration.cpp:76-104): the displacement term is integrated over the elements themselves -- all of
+    // them, or (a distance field with a threshold in the reference) the ones listed in side_faces as element ids --,
+    // every "face" here is a tri3 element; the area is the sum of the element areas
+    t.nfn = 3;
+    t.faces.clear();
+    t.mask.assign((size_t)mesh.nelems, 0u);
+    t.area = 0.;
+    std::set<int32_t> listed(side_faces, side_faces + (side_faces ? num_faces : 0));
+    for (int e = 0; e < mesh.nelems; ++e) {
+      int32_t const* en = &mesh.conn[(size_t)e * 3];
+      if (num_faces == 0 || listed.count(e)) {
+        double X[4][3];
+        for (int k = 0; k < 3; ++k)
+          for (int q = 0; q < 3; ++q) X[k][q] = mesh.coords[(size_t)en[k] * 3 + q];
+        t.area += face_area(3, X);
+        for (int k = 0; k < 4; ++k) t.faces.push_back(k < 3 ? en[k] : -1);
+      }
+      for (int n = 0; n < 3; ++n)
+        if (std::abs(mesh.coords[(size_t)en[n] * 3 + coord_idx] - coord_value) < coord_tol) t.mask[e] |= 1u << n;
+    }
+    load_plane_sums<Elem<C8_TRI3>>(mesh, t.mask, t.S);
+    return;
+  }
   int const nn = mesh.nn, nfn = (nn == 4) ? 3 : 4, nfe = (nn == 4) ? 4 : 6;
   t.nfn = nfn;
   std::set<std::vector<int32_t>> side;

@@ -183,9 +183,13 @@ int c8_status(c8_ctx* ctx);
  *                   + 1/2 balance (load - load_meas)^2 ],
  * load = internal force component `reaction_comp` summed over the nodes with |x[coord_idx] - coord_value| <
  * coord_tol.  The factor "coupled points per element" is the reference's: it adds the face integral at every
- * coupled integration point of the element (1 for tet4, 8 for this library's hex8 extension). */
+ * coupled integration point of the element (1 for tet4, 8 for this library's hex8 extension).  On a tri3 mesh the
+ * displacement term is the reference's 2-D branch (calibration.cpp:76-104, :163-222): the integral runs over the
+ * ELEMENTS -- all of them (num_faces = 0), or the listed ones (a distance field with a threshold in the reference) --
+ * and `area` is the sum of their areas. */
 typedef struct {
-  int32_t num_faces, nodes_per_face;  /* displacement side set: faces as node ids, 3 per face (tet4) or 4 (hex8) */
+  int32_t num_faces, nodes_per_face;  /* displacement side set: faces as node ids, 3 per face (tet4) or 4 (hex8); on a
+                                         tri3 mesh a list of ELEMENT ids (nodes_per_face = 1), or 0 for every element */
   const int32_t* faces;               /* HOST array [num_faces][nodes_per_face] */
   double weights[3];                  /* "displacement weights" */
   double balance_factor;

@@ -2844,12 +2844,12 @@ template <class T> static T calib_surface(Ctx const& c, Global<T> const& g, int 
   T mismatch = 0.;
   for (int q = 0; q < nq; ++q) {
     T qoi = 0.;
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < c.ndims; ++d) {
       T u_fem = 0.;
       double u_meas = 0.;
       for (int k = 0; k < nf; ++k) {
         u_fem += g.x_nodal[0][fn[k]][d] * Nf[q][k];
-        u_meas += cal.u_meas[(size_t)c.conn[e * nn + fn[k]] * 3 + d] * Nf[q][k];
+        u_meas += cal.u_meas[(size_t)c.conn[e * nn + fn[k]] * c.ndims + d] * Nf[q][k];
       }
       qoi += cal.weights[d] * (u_fem - u_meas) * (u_fem - u_meas);
     }
@@ -3254,7 +3254,23 @@ void c8o_set_calibration(void* h, int nfaces, int npf, int const* faces, double 
   cal.fnodes.assign((size_t)c->nelems * 4, 0);
   cal.load_mask.assign(c->nelems, 0u);
   cal.area = 0.;
-  int const nfe = (nn == 4) ? 4 : 6, nfn = (nn == 4) ? 3 : 4;
+  if (nn == 3) {
+    // 2-D branch (calibration.cpp:76-104): the displacement mismatch is integrated over the ELEMENTS -- all of them, or,
+    // with a distance field and threshold, those the caller lists (faces = element ids, npf = 1) -- with the order-2
+    // rule of the triangle (compute_disp_mismatch, :163-222); the area is the sum of the element areas (:88-91, :97-100)
+    std::set<int> listed(faces, faces + (faces ? nfaces : 0));
+    for (int e = 0; e < c->nelems; ++e) {
+      if (nfaces > 0 && !listed.count(e)) continue;
+      cal.nf[e] = 3;
+      double X[4][3];
+      for (int k = 0; k < 3; ++k) {
+        cal.fnodes[(size_t)e * 4 + k] = k;
+        for (int q = 0; q < 3; ++q) X[k][q] = c->coords[(size_t)c->conn[e * nn + k] * 3 + q];
+      }
+      cal.area += face_area(3, X);
+    }
+  }
+  int const nfe = (nn == 3) ? 0 : ((nn == 4) ? 4 : 6), nfn = (nn == 4) ? 3 : 4;
   for (int e = 0; e < c->nelems; ++e) {
     for (int d = 0; d < nfe; ++d) {  // downward faces; a later match overwrites an earlier one (:107-131)
       int const* loc = (nn == 4) ? TET_FACES[d] : HEX_FACES[d];
@@ -3274,13 +3290,13 @@ void c8o_set_calibration(void* h, int nfaces, int npf, int const* faces, double 
     for (int n = 0; n < nn; ++n)
       if (std::abs(c->coords[(size_t)c->conn[e * nn + n] * 3 + coord_idx] - coord_value) < coord_tol) cal.load_mask[e] |= 1u << n;
   }
-  cal.u_meas.assign((size_t)c->nnodes * 3, 0.);
+  cal.u_meas.assign((size_t)c->nnodes * c->ndims, 0.);
 }
 void c8o_set_avg_disp(void* h) { ((Ctx*)h)->qoi_kind = 0; }
 // measured data of the current step: nodal displacements ("measured_<step>" field) and the load (load input file)
 void c8o_set_measured(void* h, double const* u_meas, double load_meas) {
   Ctx* c = (Ctx*)h;
-  c->cal.u_meas.assign(u_meas, u_meas + (size_t)c->nnodes * 3);
+  c->cal.u_meas.assign(u_meas, u_meas + (size_t)c->nnodes * c->ndims);
   c->cal.load_meas = load_meas;
 }
 // preprocess_qoi for the current step: returns the total reaction load; out = {area, total load, load mismatch}

@@ -349,14 +349,15 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
     CalibrationTables t;
     calibration_tables(mesh, g_qoi.nfaces, g_qoi.side_faces.data(), g_qoi.coord_idx, g_qoi.coord_value, g_qoi.coord_tol, t);
     g_qoi.area = t.area;
-    int const npts0 = (elem_type == C8_HEX8) ? Elem<C8_HEX8>::NP0 : Elem<C8_TET4>::NP0;
+    int const npts0 = (elem_type == C8_HEX8) ? Elem<C8_HEX8>::NP0 : (elem_type == C8_TET4 ? Elem<C8_TET4>::NP0 : Elem<C8_TRI3>::NP0);
+    int const nd = elem_type == C8_TRI3 ? 2 : 3;
     double total = 0.;
     {
       Call pc = c;
       pc.what = (elem_type == C8_HEX8 && (base == K_QOI_WAVE || base == K_ADJ_JAC_WAVE || base == K_GRAD_WAVE)) ? K_QOI_WAVE : K_QOI;
       pc.staged = 0;
       pc.aa.out = &total;
-      pc.aa.qoi = QoiArgs{0., 1., g_qoi.comp, t.S.data()};
+      pc.aa.qoi = QoiArgs{0., 1., g_qoi.comp, t.S.data(), (double)nd};
       Call const saved = c;
       c = pc;
       int const rc0 = run_it();
@@ -371,11 +372,11 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
       for (size_t f = 0; f < t.faces.size() / 4; ++f) {
         int32_t const* fn = &t.faces[f * 4];
         double grad[4][3];
-        double const val = surface_mismatch_face(t.nfn, fn, mesh.coords.data(), ptrs[0], g_qoi.u_meas.data(), g_qoi.w, grad);
+        double const val = surface_mismatch_face(t.nfn, fn, mesh.coords.data(), ptrs[0], g_qoi.u_meas.data(), g_qoi.w, grad, nd);
         if (J) *J += val * scale;
         if (b0)
           for (int k = 0; k < t.nfn; ++k)
-            for (int d = 0; d < 3; ++d) b0[(size_t)fn[k] * 3 + d] -= grad[k][d] * scale;
+            for (int d = 0; d < nd; ++d) b0[(size_t)fn[k] * nd + d] -= grad[k][d] * scale;
       }
     };
     if (is_qoi) {  // Calibration<double>::evaluate + postprocess
@@ -383,7 +384,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
       *ptrs[17] += 0.5 * g_qoi.balance * g_qoi.dt_over_T * g_qoi.load_mismatch * g_qoi.load_mismatch;
       return 0;
     }
-    c.aa.qoi = QoiArgs{0., g_qoi.balance * g_qoi.dt_over_T * g_qoi.load_mismatch, g_qoi.comp, t.S.data()};
+    c.aa.qoi = QoiArgs{0., g_qoi.balance * g_qoi.dt_over_T * g_qoi.load_mismatch, g_qoi.comp, t.S.data(), (double)nd};
     int const rc = run_it();
     if (rc != 0) return rc;
     if (is_k3) surface(nullptr, ptrs[10]);

@@ -116,7 +116,8 @@ class Emul:
     # ---- Calibration objective (the emulator keeps one objective configuration, like a context) ----
     def set_calibration(self, faces, weights=(1.0, 1.0, 1.0), balance=1.0, coord_idx=1, coord_value=0.0, coord_tol=1e-8,
                         comp=1, dt_over_T=1.0):
-        self._cal = (np.ascontiguousarray(faces, dtype=np.int32), np.ascontiguousarray(weights, dtype=np.float64), balance,
+        f = np.ascontiguousarray(faces if faces is not None and len(faces) else np.zeros((0, 1)), dtype=np.int32)
+        self._cal = (f.reshape(-1, 1) if f.ndim == 1 else f, np.ascontiguousarray(weights, dtype=np.float64), balance,
                      coord_idx, coord_value, coord_tol, comp, dt_over_T)
         self._meas = None
         self.calibration = True

@@ -196,7 +196,9 @@ class Oracle:
     def set_calibration(self, faces, weights=(1.0, 1.0, 1.0), balance=1.0, coord_idx=1, coord_value=0.0,
                         coord_tol=1e-8, comp=1, dt_over_T=1.0):
         """faces: [nfaces][3 or 4] global node ids of the displacement side set; load plane: x[coord_idx] = value."""
-        f = np.ascontiguousarray(faces, dtype=np.int32)
+        f = np.ascontiguousarray(faces if faces is not None and len(faces) else np.zeros((0, 1)), dtype=np.int32)
+        if f.ndim == 1:  # tri3 meshes: a list of element ids
+            f = f.reshape(-1, 1)
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self.L.c8o_set_calibration(self.h, f.shape[0], f.shape[1], f.ctypes.data_as(ip), _d(w), balance, coord_idx,
                                    coord_value, coord_tol, comp, dt_over_T)

@@ -50,3 +50,45 @@ def test_2d_plastic_branch_ran():
     orc = ol.Oracle(et, c, conn, "small_J2", J2)
     st = two_steps(orc, c, 0.004)
     assert (st[2][2][:, :, 3] > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("model,listed", [("small_J2", False), ("small_hill_plane_stress", True)])
+def test_calibration_objective_2d(model, listed):
+    # Calibration's 2-D branch (calibration.cpp:76-104, :163-222): the displacement mismatch integrated over the elements
+    # (all of them, or a listed subset: the distance-threshold form) with the triangle's order-2 rule, the reaction load on a
+    # coordinate line, under `mechanics` (2 + 1 equations) and `mechanics_plane_stress` (one residual, thickness)
+    from parity import compare_systems, rel_vec
+    from parity_cases import HILL_PS, J2, two_steps
+    et, c, conn = mesh_2d("structured")
+    params = J2 if model == "small_J2" else HILL_PS
+    ymin = c[:, 1].min()
+    elems = [e for e in range(len(conn)) if c[conn[e]].mean(axis=0)[0] > 0.4] if listed else None
+    kw = dict(weights=(1.0, 2.0, 0.0), balance=0.3, coord_idx=1, coord_value=float(ymin), coord_tol=0.06, comp=1, dt_over_T=0.5)
+    orc, dut = ol.Oracle(et, c, conn, model, params), em.Emul(et, c, conn, model, params)
+    orc.set_calibration(elems, **kw)
+    dut.set_calibration(elems, **kw)
+    st = two_steps(orc, c, 0.004)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    u_meas = u + 1e-4 * np.random.default_rng(3).standard_normal(len(u))
+    for b in (orc, dut):
+        b.set_active(0, [0, 1, 2, 3])
+        b.set_measured(u_meas, -0.7)
+    po, pd = orc.qoi_preprocess(u, p, up, pp, xip, xi), dut.qoi_preprocess(u, p, up, pp, xip, xi)
+    assert po[0] > 0 and abs(po[1]) > 1e-3 and np.abs(po - pd).max() < 1e-12 * max(1.0, np.abs(po).max()), (po, pd)
+    Jo, Jd = orc.eval_qoi(u, p), dut.eval_qoi(u, p)
+    assert abs(Jo - Jd) < 1e-12 * abs(Jo), (Jo, Jd)
+    res = []
+    for b in (orc, dut):
+        g = np.full((orc.nelems, orc.npts, orc.nloc), 0.01)
+        f = np.full((orc.nelems, orc.npts, orc.ndofs), 0.02)
+        ls = b.new_linsys()
+        b.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, ls)
+        z_u, z_p = np.linspace(-1e-3, 1e-3, len(u)), np.linspace(2e-3, -1e-3, len(p))
+        phi = np.zeros_like(g)
+        b.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
+        res.append((ls, g, f, phi, b.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 4)))
+    (lo, go, fo, pho, gro), (ld, gd, fd, phd, grd) = res
+    errs = compare_systems(orc, ld, lo)
+    errs["g"], errs["f"], errs["phi"] = rel_vec(gd, go), rel_vec(fd, fo), rel_vec(phd, pho)
+    errs["grad"] = float(np.abs(grd - gro).max() / np.abs(gro).max())
+    assert max(errs.values()) < 1e-12, errs

@@ -216,3 +216,97 @@ def test_notch2D_adjoint_gradient_on_device_passes_fd_check():
         pm[:4] -= h * 0.1 * span
         errs.append(abs((solve(pp).qoi() - solve(pm).qoi()) / (2 * h) - gd))
     assert min(errs) < 1e-6 * abs(gd), (errs, gd)
+
+
+@pytest.mark.parametrize("model,listed,thickness", [("small_J2", False, 0.0), ("small_hill_plane_stress", True, 0.7)])
+def test_calibration_objective_2d_matches_oracle(model, listed, thickness):
+    # Calibration's 2-D branch (calibration.cpp:76-104, :163-222) on the device: element integral of the displacement
+    # mismatch (all elements / a listed subset), reaction load on the line y = ymin, under both 2-D global residuals
+    from gpu_backend import GpuBackend
+    from parity import compare_systems, rel_vec
+    from parity_cases import HILL_PS, J2, two_steps
+    et, c, conn = mesh_2d("structured")
+    params = J2 if model == "small_J2" else HILL_PS
+    elems = [e for e in range(len(conn)) if c[conn[e]].mean(axis=0)[0] > 0.4] if listed else None
+    kw = dict(weights=(1.0, 2.0, 0.0), balance=0.3, coord_idx=1, coord_value=float(c[:, 1].min()), coord_tol=0.06, comp=1, dt_over_T=0.5)
+    orc = ol.Oracle(et, c, conn, model, params)
+    gpu = GpuBackend(et, c, conn, model, params, **({"thickness": thickness} if thickness else {}))
+    if thickness:
+        orc.set_thickness(thickness)
+    orc.set_calibration(elems, **kw)
+    gpu.set_calibration(elems, **kw)
+    st = two_steps(orc, c, 0.004)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    u_meas = u + 1e-4 * np.random.default_rng(3).standard_normal(len(u))
+    for b in (orc, gpu):
+        b.set_active(0, [0, 1, 2, 3])
+        b.set_measured(u_meas, -0.7)
+    po, pd = orc.qoi_preprocess(u, p, up, pp, xip, xi), gpu.qoi_preprocess(u, p, up, pp, xip, xi)
+    assert po[0] > 0 and abs(po[1]) > 1e-3 and np.abs(po - pd).max() < 1e-12 * max(1.0, np.abs(po).max()), (po, pd)
+    Jo, Jd = orc.eval_qoi(u, p), gpu.eval_qoi(u, p)
+    assert abs(Jo - Jd) < 1e-12 * abs(Jo), (Jo, Jd)
+    res = []
+    for b in (orc, gpu):
+        g = np.full((orc.nelems, orc.npts, orc.nloc), 0.01)
+        f = np.full((orc.nelems, orc.npts, orc.ndofs), 0.02)
+        ls = b.new_linsys()
+        b.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, ls)
+        z_u, z_p = np.linspace(-1e-3, 1e-3, len(u)), np.linspace(2e-3, -1e-3, len(p))
+        phi = np.zeros_like(g)
+        b.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
+        res.append((ls, g, f, phi, b.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 4)))
+    (lo, go, fo, pho, gro), (ld, gd, fd, phd, grd) = res
+    errs = compare_systems(orc, ld, lo)
+    errs["g"], errs["f"], errs["phi"] = rel_vec(gd, go), rel_vec(fd, fo), rel_vec(phd, pho)
+    errs["grad"] = float(np.abs(grd - gro).max() / np.abs(gro).max())
+    assert max(errs.values()) < 1e-12, errs
+
+
+def test_synthetic_calibration_2d_objective_and_gradient_on_device():
+    # the FEMU set-up of test/python/notch2D_small_J2_FEMU.yaml.in in small: measurements generated with the true
+    # parameters on the notch2D mesh (full-field displacements, reaction load on ymin); at perturbed parameters the 2-D
+    # Calibration objective and its adjoint gradient, checked by central differences
+    import torch
+    from calibr8_amd import Assembler
+    from calibr8_amd.primal import PrimalDriver, adjoint_gradient
+    c, conn, ns = notch2d()
+    dbcs = [(0, 0, ns["xmin"], lambda x, y, z, t: 0.0), (0, 1, ns["ymin"], lambda x, y, z, t: 0.0),
+            (0, 1, ns["ymax"], lambda x, y, z, t: 0.001 * t)]
+    act, nsteps = [0, 1, 2, 3], 3
+    truth = np.array([1000.0, 0.25, 100.0, 2.0, 0.0, 0.0])
+
+    def solve(params, measured=None):
+        asm = Assembler(3, c, conn, "small_J2", list(params))
+        asm.set_active(0, act)
+        asm.set_qoi_calibration(None, weights=(1.0, 1.0, 0.0), balance=1e-2, coord_idx=1, coord_value=0.0, coord_tol=1e-8,
+                                comp=1, dt_over_T=1.0 / nsteps)
+        pr = PrimalDriver(asm, dbcs, max_iters=15, abs_tol=1e-12, rel_tol=1e-12).solve(nsteps)
+        if measured is not None:
+            pr.set_measured(*measured)
+        return pr
+
+    pt = solve(truth)
+    loads, zero_meas = [0.0], torch.zeros_like(pt.u[1])
+    for s in range(1, nsteps + 1):
+        pt.asm.set_measured(zero_meas, 0.0)
+        area, total, _ = pt.asm.qoi_preprocess(pt.u[s], pt.p[s], pt.u[s - 1], pt.p[s - 1], pt.xi[s - 1], pt.xi[s])
+        loads.append(total)
+    assert area > 0.5 and abs(loads[-1]) > 1e-2
+    measured = ([None] + [u.clone() for u in pt.u[1:]], loads)
+    pt.set_measured(*measured)
+    assert abs(pt.qoi()) < 1e-18
+    base = truth * np.array([1.1, 1.0, 0.8, 0.9, 1.0, 1.0])
+    pr = solve(base, measured)
+    J0 = pr.qoi()
+    assert J0 > 1e-14 and float(pr.xi[-1][:, :, 3].max()) > 1e-4
+    grad = adjoint_gradient(pr, len(act))
+    direction = np.array([100.0, 0.02, 10.0, 0.2])
+    gd = float(grad @ direction)
+    errs = []
+    for k in (2, 3, 4):
+        h = 10.0 ** (-k)
+        pp, pm = base.copy(), base.copy()
+        pp[act] += h * direction
+        pm[act] -= h * direction
+        errs.append(abs((solve(pp, measured).qoi() - solve(pm, measured).qoi()) / (2 * h) - gd))
+    assert min(errs) < 1e-6 * abs(gd), (errs, gd)
