@@ -77,6 +77,21 @@ template <class Lane> struct GpuExec {
 // XCD-aware block remap: the dispatcher deals workgroups round-robin over the 8 XCDs
 // (blocks b and b+8 share an XCD, MI355X_MICROARCH.md), so give each XCD one contiguous
 // chunk of the element order: neighbouring elements then meet in the same L2.
+// stripe > 0: XCD x takes every 8th STRIPE of `stripe` consecutive blocks instead of one contiguous eighth -- the element
+// order is then dealt out evenly and no XCD is left with the expensive (plastic) end of the mesh; the grid must be a
+// multiple of 8 * stripe (stripe_grid).  The kernels that add into shared rows with atomics keep the contiguous eighths
+// (their neighbours meet in one L2); the staged Jacobian kernels and the per-element ones use stripes: 11.02 against
+// 11.23-11.32 ms per assembly (gpurun_out/tune_xcd.log).
+#ifndef C8_TUNE_STAGE_STRIPE
+#define C8_TUNE_STAGE_STRIPE 32
+#endif
+constexpr int STAGE_STRIPE = C8_TUNE_STAGE_STRIPE;
+inline int stripe_grid(int nblocks, int stripe) { return stripe ? ((nblocks + 8 * stripe - 1) / (8 * stripe)) * (8 * stripe) : ((nblocks + 7) / 8) * 8; }
+__device__ __forceinline__ int xcd_stripe(int b, int stripe) {
+  int const x = b & 7, k = b >> 3;  // k-th block of XCD x
+  int const s = stripe > 0 ? stripe : 1;
+  return ((k / s) * 8 + x) * s + (k % s);
+}
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
 #if defined(C8_TUNE_NO_XCD_REMAP)   // tuning build (same results): blocks in launch order, round-robin over the XCDs
   return b;
@@ -134,7 +149,7 @@ k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArg
   constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLane<ModelT>;
   __shared__ WaveShared<E, ModelT<Dual>::NLOC, false, ModelT<Dual>::FINITE_DEF> shs[WPB];
-  int const lb = xcd_block(blockIdx.x, nblocks);
+  int const lb = (sa.stage && STAGE_STRIPE) ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
@@ -149,7 +164,7 @@ template <class E, template <class> class ModelT>
 static hipError_t launch_forward_wave(LaunchArgs const& a) {
   constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
-  int const grid = ((nblocks + 7) / 8) * 8;
+  int const grid = a.sa.stage ? stripe_grid(nblocks, STAGE_STRIPE) : ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_forward_jacobian_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
                      a.first, a.count, nblocks);
@@ -163,7 +178,7 @@ k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointAr
   constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLane<ModelT>;
   __shared__ WaveShared<E, ModelT<Dual>::NLOC, true, ModelT<Dual>::FINITE_DEF> shs[WPB];
-  int const lb = xcd_block(blockIdx.x, nblocks);
+  int const lb = (sa.stage && STAGE_STRIPE) ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
@@ -178,7 +193,7 @@ template <class E, template <class> class ModelT>
 static hipError_t launch_adjoint_jacobian_wave(LaunchArgs const& a) {
   constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
-  int const grid = ((nblocks + 7) / 8) * 8;
+  int const grid = a.sa.stage ? stripe_grid(nblocks, STAGE_STRIPE) : ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_adjoint_jacobian_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa,
                      a.sa, a.first, a.count, nblocks);
@@ -197,7 +212,7 @@ k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs 
   constexpr int WPB = JBLOCK / 64;
   using Lane = WaveLaneA<ModelT>;
   __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];
-  int const lb = xcd_block(blockIdx.x, nblocks);
+  int const lb = STAGE_STRIPE ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);  // per-element outputs only: stripes
   if (lb >= nblocks) return;
   int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
@@ -227,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k
 template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local_wave(LaunchArgs const& a) {
   constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
-  int const grid = ((nblocks + 7) / 8) * 8;
+  int const grid = stripe_grid(nblocks, STAGE_STRIPE);
   if (a.count <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_adjoint_local_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.sa,
                      a.first, a.count, nblocks);
