@@ -90,6 +90,11 @@ def cpu_baseline(n, nthreads):
 
 
 def main():
+    # stdout carries ONE line, the JSON result: everything else that writes to file descriptor 1 during the run (gloo's
+    # connection messages, library banners of the ranks) goes to stderr
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -412,7 +417,8 @@ def main():
             errs["xi"] = rel_vec(xi_g, xi_o)
             out["parity_max_rel_err"] = max(errs.values())
             out["speedup_vs_cpu_baseline"] = value / v
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if world > 1:
         halo.close()
         comm.close()
