@@ -109,6 +109,7 @@ class Oracle:
         self.nnodes = self.coords.shape[0]
         self.nelems = self.conn.shape[0]
         self.elem_type = elem_type
+        self.local_abs_tol = abs_tol
         params = np.atleast_2d(np.asarray(params, dtype=np.float64))
         self.nsets = params.shape[0]
         self.params = np.ascontiguousarray(params)

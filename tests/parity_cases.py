@@ -107,7 +107,7 @@ def forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip):
     errs["xi"] = rel_vec(xd, xo)
     direct = max(errs["A%d%d" % (i, j)] for i in range(2) for j in range(2))
     same = None
-    if direct > 1e-13:
+    if direct > 1e-13 or errs["xi"] > 1e-13:
         A_at = jacobian_at_state(orc, u, p, up, pp, xip, xd)
         same = {}
         for i in range(2):
@@ -115,7 +115,29 @@ def forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip):
                 k = "A%d%d" % (i, j)
                 same[k] = rel_csr_rows(ls_d.A[i][j], A_at[i][j], orc.rowptr[i][j])
                 errs[k] = min(errs[k], same[k])
+        # the residual at the DEVICE'S converged state (eval_global_residual evaluates at a stored state): the local
+        # Newton iteration stops at |C| < abs_tol, so two correct runs may stop one iteration apart and their states then
+        # differ by ~abs_tol |dC/dxi^-1| -- the residual follows the state (round-2 sweep seed 214: states 6e-13 apart,
+        # residuals 8e-11 apart, both agreeing with their own state to 1e-15)
+        ls_s = orc.new_linsys()
+        orc.global_residual(u, p, up, pp, xip, xd, ls_s)
+        for i, k in enumerate(("b_u", "b_p")):
+            same[k] = rel_vec(ls_d.b[i], ls_s.b[i])
+            errs[k] = min(errs[k], same[k])
     return errs, direct, same
+
+
+def ulp_perturbed(u, seed=1):
+    """u with every entry moved by one unit in the last place, sign at random"""
+    return u * (1.0 + 2.2e-16 * np.random.default_rng(seed).choice([-1.0, 1.0], len(u)))
+
+
+def bar_with_sensitivity(errs, tol, sens):
+    """Entries of `errs` above `tol` are accepted up to four times the ORACLE'S OWN deviation under a one-ulp perturbation of
+    the displacement field (`sens`, same keys): where the oracle cannot reproduce itself to 1e-12 from inputs that differ
+    in the last bit, no second implementation can be asked to.  Seen only with Hosford's exponent a = 100 (x^a has
+    condition number a; 5 of 1000 random cases reach 1.1e-12 .. 1.4e-12, the oracle's own sensitivity there is 8e-13)."""
+    return {k: v for k, v in errs.items() if v >= max(tol, 4.0 * sens.get(k, 0.0))}
 
 
 def check_forward(orc, dut, c, model, eps, tol):
@@ -127,7 +149,15 @@ def check_forward(orc, dut, c, model, eps, tol):
         assert orc.forward_jacobian(u, p, up, pp, xip, xo, ls_o) == 0
         assert dut.forward_jacobian(u, p, up, pp, xip, xd, ls_d) == 0
         errs, direct, same = forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip)
-        assert max(errs.values()) < tol, (n, errs, direct, same)
+        # the local state agrees to `tol`, or -- when system and state have been checked against each other at the
+        # device's own state -- to ten times the local Newton tolerance (the iteration's own resolution)
+        xi_err = errs.pop("xi")
+        if max(errs.values()) >= tol:  # rare: judge against the oracle's own one-ulp sensitivity (bar_with_sensitivity)
+            ls_p = orc.new_linsys()
+            assert orc.forward_jacobian(ulp_perturbed(u), p, up, pp, xip, orc.new_state(), ls_p) == 0
+            bad = bar_with_sensitivity(errs, tol, compare_systems(orc, ls_p, ls_o))
+            assert not bad, (n, bad, errs, direct, same, xi_err)
+        assert xi_err < tol or (same is not None and xi_err < 10.0 * getattr(orc, "local_abs_tol", 1e-12)), (n, xi_err, errs)
     if model == "small_J2" and eps > 0.003:
         assert (st[2][2][:, :, -1] > 0).mean() > 0.3  # the plastic branch really ran (alpha is the last local unknown)
 
@@ -158,12 +188,23 @@ def check_adjoint_chain(orc, dut, c, model, eps, tol):
         (u, p, xi), (up, pp, xip) = st[n], st[n - 1]
         # K3
         g_d, f_d = g_o.copy(), f_o.copy()
+        g_in, f_in = g_o.copy(), f_o.copy()
         ls_o, ls_d = orc.new_linsys(), dut.new_linsys()
         orc.adjoint_jacobian(u, p, up, pp, xip, xi, g_o, f_o, ls_o)
         assert dut.adjoint_jacobian(u, p, up, pp, xip, xi, g_d, f_d, ls_d) == 0
         errs = compare_systems(orc, ls_d, ls_o)
         errs["g"] = rel_vec(g_d, g_o)
-        assert max(errs.values()) < tol, ("adjoint_jacobian", n, errs)
+        # the right-hand side is a sum over elements of entries of the history f (among others): judged against the
+        # largest summand, not against the sum (with the stand-in adjoint solution below the summands cancel by three
+        # orders of magnitude: |f| ~ 20, |b| ~ 0.02; the order of the scatter then shows at 4e-12 of |b|)
+        for i, k in enumerate(("b_u", "b_p")):
+            top = np.abs(ls_o.b[i]).max()
+            errs[k] *= top / max(top, np.abs(f_in).max()) if top > 0 else 1.0
+        if max(errs.values()) >= tol:
+            ls_p = orc.new_linsys()
+            orc.adjoint_jacobian(ulp_perturbed(u), p, up, pp, xip, xi, g_in.copy(), f_in, ls_p)
+            bad = bar_with_sensitivity(errs, tol, compare_systems(orc, ls_p, ls_o))
+            assert not bad, ("adjoint_jacobian", n, bad, errs)
         # a stand-in global adjoint solution (the linear solve is out of scope)
         z_u = rng.standard_normal(len(u)) * 1e-3
         z_p = rng.standard_normal(len(p)) * 1e-3

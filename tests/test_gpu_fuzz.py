@@ -53,3 +53,58 @@ def test_random_case_matches_oracle(seed):
     check_residual(orc, gpu, c, eps, tol)
     if not (kind == "hex8" and kernel == "slot" and scatter == "gather"):  # that adjoint kernel cannot stage (refused)
         check_adjoint_chain(orc, gpu, c, model, eps, tol)
+
+
+# ---- the model families added in round 2: 2-D plane strain / plane stress on tri3, Hosford / Barlat on tet4 and hex8 -------
+def random_case_r2(seed):
+    from meshes import jiggle_2d, tri_mesh
+    from parity_cases import CASES_2D, CASES_LINE_SEARCH, CASES_PLANE_STRESS
+    rng = np.random.default_rng(5000 + seed)
+    pool = [(m, p, "2d") for m, p, _ in CASES_2D[1:]] + [(m, p, "2d") for m, p, _ in CASES_PLANE_STRESS[1:]] + \
+           [(m, p, "3d") for m, p, _ in CASES_LINE_SEARCH]
+    model, p0, fam = pool[rng.integers(len(pool))]
+    p = np.array(p0, dtype=np.float64)
+    scale = 1.0 + 0.2 * (rng.random(len(p)) - 0.5) * (np.abs(p) > 0)
+    if model == "hypo_hill_plane_stress":
+        scale[9:] = 1.0  # the material axes stay a rotation
+    if model in ("small_hosford", "hypo_hosford", "hypo_barlat"):
+        scale[3] = 1.0   # the exponent a
+    p = p * scale
+    p[1] = min(p[1], 0.4)
+    eps = float(10 ** rng.uniform(-3.0, -2.2))
+    if fam == "2d":
+        nx, ny = (int(v) for v in rng.integers(3, 8, 2))
+        c, conn, sets = tri_mesh(nx, ny, *(0.5 + rng.random(2)))
+        c = jiggle_2d(c, sets, 0.02 + 0.05 * rng.random(), seed=seed)
+        return model, list(p), ol.TRI3, c, conn, eps, ["colored", "atomic"][rng.integers(2)]
+    kind = ["hex8", "tet4"][rng.integers(2)]
+    n = tuple(int(v) for v in rng.integers(2, 4, 3))
+    c, conn, sets = brick(n[0], n[1], n[2], *(0.5 + rng.random(3)))
+    c = jiggle(c, sets, 0.02 + 0.06 * rng.random(), seed=seed)
+    if kind == "tet4":
+        tets = [[0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6], [0, 5, 1, 6]]
+        conn = np.concatenate([conn[:, t] for t in tets]).astype(np.int32)
+    return model, list(p), (ol.HEX8 if kind == "hex8" else ol.TET4), c, conn, eps, ["colored", "atomic", None][rng.integers(3)]
+
+
+def run_case_r2(factory, seed, tol=1e-12):
+    from parity_cases import LOCAL_LINE_SEARCH
+    model, params, et, c, conn, eps, scatter = random_case_r2(seed)
+    ls = model in ("small_hosford", "hypo_hosford", "hypo_barlat")
+    orc = ol.Oracle(et, c, conn, model, params)
+    if ls:
+        orc.set_local_line_search(*LOCAL_LINE_SEARCH)
+    dut = factory(et, c, conn, model, params, scatter, LOCAL_LINE_SEARCH if ls else None)
+    check_forward(orc, dut, c, model, eps, tol)
+    check_residual(orc, dut, c, eps, tol)
+    check_adjoint_chain(orc, dut, c, model, eps, tol)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("C8_FUZZ_SEEDS_R2", "24"))))
+def test_random_case_of_the_round2_families_matches_oracle(seed):
+    from gpu_backend import GpuBackend
+
+    def factory(et, c, conn, model, params, scatter, ls):
+        return GpuBackend(et, c, conn, model, params, scatter=scatter, **({"line_search": ls} if ls else {}))
+
+    run_case_r2(factory, seed)
