@@ -238,7 +238,7 @@ C8_HD bool gj_solve_cols(EX& ex, GetM getm, Col col, GetB getb, Active active) {
           col(lane, r) = hit ? ms : col(lane, r);
         });
       }
-      double const inv = 1. / cpiv;
+      double const inv = c8_rcp(cpiv);
       double const bsn = bpiv * inv;
       b[s] = bsn;
       C8_UNROLL
@@ -296,7 +296,7 @@ C8_HD bool gj_solve_xlane(EX& ex, Col col, GetB getb, Active active) {
           col(lane, r) = (hit && mine) ? ms : col(lane, r);  // the owner of the pivot column leaves it as broadcast
         });
       }
-      double const inv = 1. / cpiv;
+      double const inv = c8_rcp(cpiv);
       double const bsn = bpiv * inv;
       b[s] = bsn;
       C8_UNROLL
@@ -366,7 +366,7 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
         col[r] = hit ? cs : col[r];
         b[r] = hit ? bs : b[r];
       });
-      double const inv = 1. / cpiv;
+      double const inv = c8_rcp(cpiv);
       double const bsn = bpiv * inv;
       b[s] = bsn;
       C8_UNROLL

@@ -71,12 +71,27 @@ C8_HD double val(Dual const& x) { return x.v; }
 C8_HD double der(double) { return 0.; }
 C8_HD double der(Dual const& x) { return x.d; }
 
+// 1 / x on the device: v_rcp_f64 and two Newton steps -- accurate to the last place but not correctly rounded, and half the
+// dependent instructions of the IEEE division sequence (div_scale x 2, rcp, 4-5 fma, div_fmas, div_fixup); the reciprocals
+// sit on the critical path of every evaluation of a model (11.00 against 11.12 ms per assembly, gpurun_out/tune_rcp.log).
+// 0 and infinities give NaN instead of inf / 0: the callers divide by zero only where IEEE gives NaN as well (0 / 0 on
+// stress-free points, whose branch does not use the quotient).  C8_TUNE_IEEE_DIV: tuning build with the IEEE sequence.
+C8_HD double c8_rcp(double x) {
+#if !defined(C8_TUNE_IEEE_DIV) && defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.), r, r);
+  r = fma(fma(-x, r, 1.), r, r);
+  return r;
+#else
+  return 1. / x;
+#endif
+}
 C8_HD Dual operator-(Dual const& a) { return Dual(-a.v, -a.d); }
 C8_HD Dual operator+(Dual const& a, Dual const& b) { return Dual(a.v + b.v, a.d + b.d); }
 C8_HD Dual operator-(Dual const& a, Dual const& b) { return Dual(a.v - b.v, a.d - b.d); }
 C8_HD Dual operator*(Dual const& a, Dual const& b) { return Dual(a.v * b.v, a.v * b.d + a.d * b.v); }
 C8_HD Dual operator/(Dual const& a, Dual const& b) {
-  double const r = 1. / b.v;
+  double const r = c8_rcp(b.v);
   double const q = a.v * r;
   return Dual(q, (a.d - q * b.d) * r);
 }
@@ -87,11 +102,11 @@ C8_HD Dual operator-(double a, Dual const& b) { return Dual(a - b.v, -b.d); }
 C8_HD Dual operator*(Dual const& a, double b) { return Dual(a.v * b, a.d * b); }
 C8_HD Dual operator*(double a, Dual const& b) { return Dual(a * b.v, a * b.d); }
 C8_HD Dual operator/(Dual const& a, double b) {
-  double const r = 1. / b;
+  double const r = c8_rcp(b);
   return Dual(a.v * r, a.d * r);
 }
 C8_HD Dual operator/(double a, Dual const& b) {
-  double const r = 1. / b.v;
+  double const r = c8_rcp(b.v);
   double const q = a * r;
   return Dual(q, -q * b.d * r);
 }
