@@ -49,12 +49,16 @@ def lbfgs_minimize(fun, x0, lo=None, hi=None, max_iters=20, grad_tol=1e-12, step
 
 
 class InverseProblem:
-    """Adjoint_Objective on one part: value = sum over steps of eval_qoi after a primal solve with the trial
-    parameters, gradient = the adjoint march, both in canonical variables with bound scaling to [-1, 1]
-    (objective.cpp:41-61, :125-137).  `make_primal(params)` returns a solved PrimalDriver for the full physical
-    parameter vector of element set 0 (with measured data attached when the objective needs it)."""
+    """Adjoint_Objective: value = sum over steps of eval_qoi after a primal solve with the trial parameters, gradient =
+    the adjoint march, both in canonical variables with bound scaling to [-1, 1] (objective.cpp:41-61, :125-137).
+    `make_primal(params)` returns a solved PrimalDriver for the full physical parameter vector of element set 0 (with
+    measured data attached when the objective needs it).  On a multi-part mesh every rank runs the same loop on its part
+    (`make_primal` builds the part's driver with the distributed linear solve) and `comm` (distributed.Comm) sums the
+    objective and the gradient over the parts (PCU_Add_Double(J), adjoint_objective.cpp:39,99; PCU_Add_Doubles(grad),
+    :109): all ranks then take the same L-BFGS steps."""
 
-    def __init__(self, make_primal, base_params, active, bounds):
+    def __init__(self, make_primal, base_params, active, bounds, comm=None):
+        self.comm = comm
         self.make_primal = make_primal
         self.base = np.array(base_params, dtype=np.float64)
         self.active = [int(a) for a in active]
@@ -87,10 +91,18 @@ class InverseProblem:
         try:
             pr = self.make_primal(params)
         except (RuntimeError, _l.C8Error):
-            return None  # the forward problem failed at these parameters (adjoint_objective.cpp lets ROL back off)
+            pr = None  # the forward problem failed at these parameters (adjoint_objective.cpp lets ROL back off)
+        if self.comm is not None:  # every part backs off together
+            if self.comm.allreduce(np.array([0.0 if pr is not None else 1.0]))[0] > 0.0:
+                return None
+        elif pr is None:
+            return None
         pr.asm.set_active(0, self.active)
         J = pr.qoi()
         g = np.ascontiguousarray(adjoint_gradient(pr, len(self.active)))
+        if self.comm is not None:
+            red = self.comm.allreduce(np.concatenate([[J], g]))
+            J, g = float(red[0]), np.ascontiguousarray(red[1:])
         canon = np.ascontiguousarray(canonical, dtype=np.float64)
         gc = np.zeros_like(g)
         _l.check(L.c8_transform_gradient(len(g), g.ctypes.data_as(_l.dp), canon.ctypes.data_as(_l.dp),

@@ -469,6 +469,91 @@ def test_calibration_objective_over_two_parts():
         assert np.abs(out[r]["grad"] - grad_ref).max() < 1e-11 * np.abs(grad_ref).max(), (r, out[r]["grad"], grad_ref)
 
 
+# ---- the calibration loop over two parts (BASELINE config 5 in small): InverseProblem with the parts' communicator ---------
+def inverse_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from calibr8_amd import Assembler, InverseProblem, PrimalDriver
+        from calibr8_amd import distributed as D
+        from calibr8_amd.primal import distributed_scipy_solver
+        from meshes import brick
+        n = (4, 4, 2)
+        c, conn, sets = brick(n[0], n[1], n[2], 1.0, 1.5, 1.0)
+        ep = (c[conn].mean(axis=1)[:, 0] > 0.5).astype(np.int32)
+        part = D.part_from_global(c, conn, ep, rank, world)
+        plan = D.HaloPlan(part, dist)
+        gid, no = plan.node_gid, part.nowned
+        lc = c[gid]
+        comm = D.Comm.host(dist, rank, world)
+        nsteps, truth, active = 2, np.array(J2), [2, 3]
+        kw = dict(weights=(1.0, 1.0, 1.0), balance=1e-2, coord_idx=1, coord_value=0.0, coord_tol=1e-8, comp=1, dt_over_T=1.0 / nsteps)
+
+        def bcs(coords, nlim):
+            of = lambda ax, v: np.nonzero(np.abs(coords[:nlim, ax] - v) < 1e-9)[0].astype(np.int32)
+            zero = lambda x, y, z, t: 0.0
+            return [(0, 0, of(0, 0.0), zero), (0, 1, of(1, 0.0), zero), (0, 2, of(2, 0.0), zero),
+                    (0, 1, of(1, 1.5), lambda x, y, z, t: 0.0035 * t)]
+
+        def faces_of(coords, cn):
+            return np.array([[int(e[k]) for k in f] for e in cn for f in LOC if all(abs(coords[e[k], 0] - 1.0) < 1e-9 for k in f)],
+                            dtype=np.int32).reshape(-1, 4)
+
+        # single-part truth run: the measurements (every rank runs it: small)
+        def whole(params, measured=None):
+            asm = Assembler(8, c, conn, "small_J2", list(params))
+            asm.set_qoi_calibration(faces_of(c, conn), **kw)
+            pr = PrimalDriver(asm, bcs(c, len(c)), max_iters=20, abs_tol=1e-12, rel_tol=1e-12).solve(nsteps)
+            if measured is not None:
+                pr.set_measured(*measured)
+            return pr
+
+        pt = whole(truth)
+        loads, zm = [0.0], torch.zeros_like(pt.u[1])
+        for s_ in range(1, nsteps + 1):
+            pt.asm.set_measured(zm, 0.0)
+            loads.append(pt.asm.qoi_preprocess(pt.u[s_], pt.p[s_], pt.u[s_ - 1], pt.p[s_ - 1], pt.xi[s_ - 1], pt.xi[s_])[1])
+        meas_whole = ([None] + [u.clone() for u in pt.u[1:]], loads)
+        gidx = torch.as_tensor((gid[:, None] * 3 + np.arange(3)).ravel(), device=pt.u[1].device)
+        meas_part = ([None] + [u[gidx].contiguous() for u in pt.u[1:]], loads)
+        keep = []
+
+        def part_primal(params):
+            asm = Assembler(8, lc, part.conn, "small_J2", list(params), extra_pairs=plan.extra_pairs)
+            halo = D.Halo(plan, asm.rowptr[1][1], asm.colidx[1][1], asm, comm)
+            keep.append(halo)
+            asm.set_qoi_calibration(faces_of(lc, part.conn), **kw)
+            pr = PrimalDriver(asm, bcs(lc, len(lc)), max_iters=20, abs_tol=1e-12, rel_tol=1e-12,
+                              solver=distributed_scipy_solver(asm, plan, dist)).solve(nsteps)
+            pr.set_measured(*meas_part)
+            return pr
+
+        bounds, start = [[50.0, 200.0], [1.0, 4.0]], np.array([150.0, 3.0])
+        inv = InverseProblem(part_primal, truth, active, bounds, comm=comm)
+        found, info = inv.solve(start, max_iters=6, grad_tol=1e-14, step_tol=1e-12, max_ls_evals=8)
+        ref = InverseProblem(lambda prm: whole(prm, meas_whole), truth, active, bounds)
+        rfound, rinfo = ref.solve(start, max_iters=6, grad_tol=1e-14, step_tol=1e-12, max_ls_evals=8)
+        out[rank] = dict(found=found, rfound=rfound, f=info["f"], rf=rinfo["f"], evals=info["evals"], revals=rinfo["evals"],
+                         info={k: str(v) for k, v in info.items()}, rinfo={k: str(v) for k, v in rinfo.items()},
+                         hist=[(list(p_), j) for p_, j in inv.history], rhist=[(list(p_), j) for p_, j in ref.history])
+        for h in keep:
+            h.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_inverse_problem_over_two_parts_takes_the_single_part_iterates():
+    out = spawn(inverse_worker, 2)
+    for r in range(2):
+        res = out[r]
+        assert res["evals"] == res["revals"] and len(res["hist"]) == len(res["rhist"]) > 3, (r, res["info"], res["rinfo"])
+        for (p1, j1), (p2, j2) in zip(res["hist"], res["rhist"]):  # the same trial parameters and objective values, step by step
+            assert np.abs(np.array(p1) / np.array(p2) - 1.0).max() < 1e-6 and abs(j1 - j2) < 1e-6 * max(abs(j2), 1e-30), (r, p1, p2, j1, j2)
+        assert res["f"] < 1e-3 * res["hist"][0][1]  # the objective went down by three orders in six iterations
+    assert out[0]["hist"] == out[1]["hist"]  # both ranks took identical steps
+
+
 # ---- the RCCL transport itself, one rank (RCCL admits one rank per card) ---------------------------------------------
 def test_rccl_transport_single_rank_self_exchange():
     """librccl through dlopen, ncclCommInitRank, grouped ncclSend / ncclRecv on the comm stream ordered against the
