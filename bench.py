@@ -104,7 +104,7 @@ def main():
                     help="gather (default): staged assembly + row sums, no atomics, bitwise reproducible, fastest")
     ap.add_argument("--cpu-sample", type=int, default=32, help="edge of the CPU-baseline sample brick")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave", "wave_ad"])
     ap.add_argument("--stage-chunk", type=int, default=0, help="scatter=gather: minimum elements per staged chunk")
     ap.add_argument("--assign", action="store_true", help="scatter=gather: c8_set_assign_mode (zero_all + assembly in one call); "
                     "NOT the default: the contract metric is the accumulate-into assembly")
@@ -282,6 +282,12 @@ def main():
         asm.set_assign_mode(True)  # zero_all + assembly in one call (c8_set_assign_mode): no zeroing pass, no read of the old values
         also["ms_per_step_assign_mode"] = timed(step, reps)
         asm.set_assign_mode(False)
+    if args.kernel in ("auto", "wave"):
+        # the same step with the local Newton iteration and the AD passes kept in the kernel (C8_KERNEL_WAVE_AD): what every
+        # model without a closed form runs, and what round 1 timed
+        asm.set_kernel("wave_ad")
+        also["ms_per_step_iterated_ad_form"] = timed(step, reps)
+        asm.set_kernel(args.kernel)
     assert asm.status() == 0
 
     overlap_check = None
@@ -330,6 +336,10 @@ def main():
                                   " = the %d^3 brick (BASELINE config 4) split %dx%dx%d" % ((n,) + tuple(pdims)) if args.scaling == "strong" and world > 1 else ""),
                    "elements_per_gpu": asm.nelems, "elements_total": nelems_total, "plastic_fraction": plastic_frac,
                    "scatter": args.scatter, "kernel": args.kernel,
+                   "local_solve": "iterated: local Newton + forward-mode AD in the kernel (C8_KERNEL_WAVE_AD)" if args.kernel in ("slot", "wave_ad")
+                                  else "closed form of small_J2 (radial return + consistent tangent, same state and Jacobian "
+                                       "to 2e-13; the library's default); also.ms_per_step_iterated_ad_form times the "
+                                       "Newton + AD form of the same kernel",
                    "colors": asm.ncolors, "part_grid": list(pdims),
                    "parallelism": "one element block per GPU; ghost rows of A and b ADDed into their owners: HIP pack kernel, "
                                   "one grouped ncclSend/ncclRecv message per neighbour (RCCL over xGMI), HIP unpack-add kernel "
@@ -346,12 +356,12 @@ def main():
         balg = algorithmic_bytes(asm.nelems, asm.nnodes, nnz_total)
         achieved = balg / (kernel_ms * 1e-3) / 1e9
         prof, prof_other = pmc_profile(block[0] if block[0] == block[1] == block[2] else -1, args.scatter,
-                                       "slot" if args.kernel == "slot" else "wave", build_id)
+                                       args.kernel if args.kernel in ("slot", "wave_ad") else "wave", build_id)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
                            "traffic": prof.get("traffic_bytes_per_launch") if prof else None,
                            "algorithmic_bytes_per_step": balg, "kernel_ms_per_step": kernel_ms,
-                           "kernel": ("k_forward_jacobian" if args.kernel == "slot" else "k_forward_jacobian_wave") +
+                           "kernel": {"slot": "k_forward_jacobian", "wave_ad": "k_forward_jacobian_wave"}.get(args.kernel, "k_forward_jacobian_wave_closed") +
                                      ("<hex8,small_J2> into the element stage + k_gather_rows, per chunk of elements"
                                       if args.scatter == "gather" else "<hex8,small_J2> (%d launches per step)"
                                       % (asm.ncolors if args.scatter == "colored" else 1))}

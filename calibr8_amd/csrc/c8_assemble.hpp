@@ -53,6 +53,7 @@ struct ModelSettings {
   // `line search:` sublist of the local residual (line_search.hpp:28-49; Hosford / Barlat models)
   double ls_c1 = 1.e-4, ls_bmin = 0.5, ls_bmax = 0.9;
   int ls_max_evals = 4;
+  int closed_form = 0;  // forward wave kernel: the model's closed form where it has one (c8_set_kernel_variant)
 };
 struct FieldArgs {
   double const* u;        // [nnodes][3]

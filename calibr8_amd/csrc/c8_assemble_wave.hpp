@@ -21,6 +21,9 @@
 // sets (hex8): the two ip sets are fused by adding the pressure-mass flux to V_p.
 #pragma once
 // Diagnostic build only (-DC8_STAMPS, tools/stamp_phases.py): s_memtime stamps at phase boundaries.
+#ifndef C8_CLOSED_P2
+#define C8_CLOSED_P2 1  // timing switch: 0 = the closed-form kernel keeps the (flux group, column) lanes of phase P
+#endif
 #ifdef C8_STAMPS
 #define C8_STAMP(i) ex.stamp(sa, e, i)
 #else
@@ -96,7 +99,8 @@ template <class E, class R, class SH> C8_HD void commit_cached_shape(R const& r,
 
 // ADJ / PREV: the arrays only the adjoint assembly / only finite-deformation models use are left out of the other
 // instantiations (one entry instead): 17.7 KB instead of 19.2 KB for the forward assembly of a small-strain model.
-template <class E, int NL, bool ADJ = true, bool PREV = true> struct WaveShared {
+// NOSOLVE: the closed-form forward kernel has no local elimination and leaves out the matrices M (4.6 KB).
+template <class E, int NL, bool ADJ = true, bool PREV = true, bool NOSOLVE = false> struct WaveShared {
   static constexpr int NLP = 8;  // lanes per point in phase N
   double X[E::NN][3];
   double u[E::NN][3], p[E::NN];
@@ -104,13 +108,13 @@ template <class E, int NL, bool ADJ = true, bool PREV = true> struct WaveShared 
   double N[E::NP0][E::NN];
   double dN[E::NP0][E::NN][3];
   double wdv[E::NP0];
-  double M[E::NP0][NLP][NLP + 1];   // dC/dxi per point
+  double M[NOSOLVE ? 1 : E::NP0][NLP][NLP + 1];   // dC/dxi per point
   double q[E::NP0][WQ];             // interpolated values
   double qprev[PREV ? E::NP0 : 1][9];  // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
   double xip[E::NP0][NLP];          // previous local state
   double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
-  double F[E::NP0][WQ];             // flux values
+  double F[E::NP0][WF];             // flux values
   double gh[ADJ ? E::NP0 : 1][NLP]; // adjoint: local history g at each point
   double rq[ADJ ? 4 : 1][WQ + 1];   // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
   double h;
@@ -126,7 +130,8 @@ template <template <class> class ModelT> struct WaveLane {
   PointState<Dual> g;
   double b[Model::NLOC];
   double J[16];   // phase P: rows of this lane's half, column b
-  double R;
+  double J1[16];  // closed-form forward kernel: the rows of flux group 1 (phase P there), otherwise unused
+  double R, Rx;
   // issued with the first loads of the element, used much later: the previous / current local state of this lane's
   // (point, direction) and the eight CSR positions of this lane's column node (their round trips would otherwise
   // be exposed after the shape tables and in front of the scatter)
@@ -389,7 +394,7 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
 // ADJOINT = true : eval_adjoint_jacobian (evaluations.cpp:349-526): no local solve (stored xi), the element
 //                  matrix is scattered transposed, and the right-hand side is -dJ/dx + f + (dxi/dx)^T g with
 //                  g -= dJ/dxi updated in place; every x-derivative goes through the point quantities q.
-template <class E, template <class> class ModelT, class QoI, bool ADJOINT, class EX, class SH>
+template <class E, template <class> class ModelT, class QoI, bool ADJOINT, bool CLOSED = false, class EX, class SH>
 C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings const& ms,
                          FieldArgs const& fa, AdjointArgs const& aa, SystemArgs const& sa, int e) {
   using Model = ModelT<Dual>;
@@ -405,7 +410,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     r.failed = false;
     r.R = 0.;
     C8_UNROLL
-    for (int a = 0; a < 16; ++a) r.J[a] = 0.;
+    for (int a = 0; a < 16; ++a) r.J[a] = r.J1[a] = 0.;
     if (lane == 0) sh.failed = 0;
     {
       int const pt = lane >> 3, d = lane & 7;
@@ -471,6 +476,8 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
 
   C8_STAMP(1);
   {
+  bool need_inverse = false;
+  if constexpr (!CLOSED) {  // CLOSED: the model's closed form replaces phases N, the inverse and the AD passes of phase D
   // ---- phase N: local Newton at all 8 points (small_J2.cpp:122-173) ---------------------------
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
@@ -564,7 +571,6 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   //      of phase D then apply it as a matrix-vector product instead of two more eliminations.  When every
   //      point of the element took the elastic branch dC/dxi is exactly I (R = xi - xi_trial) and the
   //      elimination is skipped: solving I x = b returns b unchanged, so the result is bitwise the same.
-  bool need_inverse = false;
   if (Model::HAS_LOCAL) {
     need_inverse = ex.any_wave([&](int lane) {
       int const pt = lane >> 3, d = lane & 7;
@@ -600,9 +606,35 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     }
   }
 
+  }  // !CLOSED
   C8_STAMP(3);
   // ---- phases D and P, 4 points per pass -------------------------------------------------------------
   for (int t = 0; t < 2; ++t) {
+    if constexpr (CLOSED) {
+      // the model's closed form (Model::closed_form): lane (ql, c) solves point 4 t + ql (all sixteen lanes of a point the
+      // same few dozen operations) and writes column c of its d flux / d q; lane c = 0 also stores the state and the fluxes
+      ex.each([&](int lane) {
+        int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
+        int const es = mt.elem_set ? mt.elem_set[e] : 0;
+        typename Model::ClosedForm cf;
+        Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, sh.q[pt], sh.xip[pt], ms.abs_tol, sh.h, ms.stab_mult, cf);
+        double col[WF];
+        Model::closed_form_column(cf, c, col);
+        double const w = sh.wdv[pt];
+        constexpr int LD = WQ + 1;
+        double* Dc = &sh.D[ql][0][c];
+        C8_UNROLL
+        for (int rr = 0; rr < WF; ++rr) Dc[rr * LD] = w * col[rr];
+        if (c == 0) {
+          size_t const q0 = ((size_t)e * E::NP0 + pt) * NL;
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) { fa.xi[q0 + j] = cf.xi[j]; sh.xi[pt][j] = cf.xi[j]; }
+          double* Fp = sh.F[pt];
+          C8_UNROLL
+          for (int rr = 0; rr < WF; ++rr) Fp[rr] = w * cf.F[rr];
+        }
+      });
+    } else
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
       int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
@@ -672,6 +704,47 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     //   g = 1: entries (node n, u_2) from flux rows 6..8 and (n, p)   from flux rows 9..12
     // Both halves run one instruction stream: entry E0 takes rows r0..r0+2, entry E1 rows r1..r1+2 plus
     // row 9 with weight zf (zero for g = 0).  J[2n] = E0 of node n, J[2n+1] = E1 of node n.
+    if constexpr (CLOSED && !ADJOINT && C8_CLOSED_P2) {
+    // phase P of the closed-form kernel: lane = (point half hf, column b).  Each half takes two of the pass's four points
+    // and ALL 32 rows of column b, so the eight nodes' shape entries (the same for every lane of a half) are read once
+    // per point for 13 products instead of 7: a third fewer LDS reads, which bound this phase.  The
+    // accumulators are J (rows (n, u_0), (n, u_1): flux group 0) and J1 (rows (n, u_2), (n, p): flux group 1); the two
+    // halves' partial sums are exchanged once per element, after the last pass.
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const b = lane & 31, hf = lane >> 5;
+      bool const bu = b < 3 * E::NN;
+      int const m = bu ? b / 3 : b - 3 * E::NN;
+      int const k = bu ? b - 3 * m : 0;
+      int const cg = bu ? 3 * k : 10;
+      int const cv = bu ? 13 + k : 9;
+      bool const has_cv = Mechanics::USES_U || !bu;
+      int const cvl = has_cv ? cv : 9;
+      C8_NOUNROLL
+      for (int q2 = 0; q2 < 2; ++q2) {
+        int const ql = 2 * hf + q2, pt = 4 * t + ql;
+        double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
+        double const bNv = has_cv ? bN : 0.;
+        double const bNp = bu ? 0. : bN;
+        double db[WF];
+        C8_UNROLL
+        for (int rr = 0; rr < WF; ++rr) {
+          double const* Dr = sh.D[ql][rr];
+          db[rr] = Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cvl] * bNv;
+        }
+        C8_UNROLL
+        for (int n = 0; n < E::NN; ++n) {
+          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+          r.J[2 * n] += a0 * db[0] + a1 * db[1] + a2 * db[2];
+          r.J[2 * n + 1] += a0 * db[3] + a1 * db[4] + a2 * db[5];
+          r.J1[2 * n] += a0 * db[6] + a1 * db[7] + a2 * db[8];
+          r.J1[2 * n + 1] += a0 * db[10] + a1 * db[11] + a2 * db[12] + aN * db[9];
+        }
+        double const* Fp = sh.F[pt];
+        r.R += Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * bNp;
+      }
+    });
+    } else
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
       int const b = lane & 31, g = lane >> 5;
@@ -732,6 +805,29 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     });
     ex.sync();
     C8_STAMP(5 + 2 * t);
+  }
+  if constexpr (CLOSED && !ADJOINT && C8_CLOSED_P2) {
+    // the halves exchange their partial sums: half 0 completes group 0 (J), half 1 completes group 1 (J1) and moves it
+    // into J, which the scatter reads
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const hf = lane >> 5;
+      C8_UNROLL
+      for (int k = 0; k < 16; ++k) {
+        double const recv = ex.xor32(lane, [&](int l) { auto& rl = ex.lane(l); return (l >> 5) ? rl.J[k] : rl.J1[k]; });
+        if (hf) r.J1[k] += recv; else r.J[k] += recv;
+      }
+      double const Rr = ex.xor32(lane, [&](int l) { return ex.lane(l).R; });
+      r.Rx = Rr;
+    });
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      if (lane >> 5) {
+        C8_UNROLL
+        for (int k = 0; k < 16; ++k) r.J[k] = r.J1[k];
+      }
+      r.R += r.Rx;
+    });
   }
 
   }
@@ -931,6 +1027,14 @@ C8_HD void forward_jacobian_wave(EX& ex, SH& sh, MeshTables const& mt,
                                  ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
   jacobian_wave<E, ModelT, PointQoi, false>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
 }
+// K1 with the model's closed form in place of the local Newton iteration and the AD passes (Model::HAS_CLOSED_FORM)
+template <class E, template <class> class ModelT, class EX, class SH>
+C8_HD void forward_jacobian_wave_closed(EX& ex, SH& sh, MeshTables const& mt,
+                                        ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
+  jacobian_wave<E, ModelT, PointQoi, false, true>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
+}
+template <class M, class = void> struct has_closed_form : std::false_type {};
+template <class M> struct has_closed_form<M, std::enable_if_t<M::HAS_CLOSED_FORM>> : std::true_type {};
 
 template <class E, template <class> class ModelT, class QoI, class EX, class SH>
 C8_HD void adjoint_jacobian_wave(EX& ex, SH& sh, MeshTables const& mt,

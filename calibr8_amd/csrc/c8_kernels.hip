@@ -62,6 +62,8 @@ template <class Lane> struct GpuExec {
     bool const upper = (k & 8) != 0;
     return __hiloint2double(upper ? b_hi : a_hi, upper ? b_lo : a_lo);
   }
+  // get(l) of lane l ^ 32 (the other half of the wavefront)
+  template <class F> __device__ __forceinline__ double xor32(int lane, F get) { return __shfl_xor(get(lane), 32); }
 #ifdef C8_STAMPS
   // element e is sampled when e % 244 == 0 (4096 samples over a 1M-element mesh)
   __device__ __forceinline__ void stamp(SystemArgs const& sa, int e, int i) {
@@ -160,12 +162,41 @@ k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArg
   forward_jacobian_wave<E, ModelT>(ex, shs[wib], mt, ms, fa, sa, e);
 }
 
+#ifndef C8_CLOSED_WAVES
+#define C8_CLOSED_WAVES 3  // 156 registers, 13.5 KB of LDS per wave: three waves per SIMD measured 0.6 % ahead of two
+#endif
+// K1 with the model's closed form (Model::HAS_CLOSED_FORM): no local Newton iteration, no local elimination, no AD passes
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(JBLOCK) __attribute__((amdgpu_waves_per_eu(C8_CLOSED_WAVES, C8_CLOSED_WAVES)))
+k_forward_jacobian_wave_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+                                                                         int first, int count, int nblocks) {
+  constexpr int WPB = JBLOCK / 64;
+  using Lane = WaveLane<ModelT>;
+  __shared__ WaveShared<E, ModelT<Dual>::NLOC, false, ModelT<Dual>::FINITE_DEF, true> shs[WPB];
+  int const lb = (sa.stage && STAGE_STRIPE) ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int const gi = lb * WPB + wib;
+  if (gi >= count) return;
+  int const e = mt.order ? mt.order[first + gi] : first + gi;
+  Lane L;
+  GpuExec<Lane> ex(lane, L);
+  forward_jacobian_wave_closed<E, ModelT>(ex, shs[wib], mt, ms, fa, sa, e);
+}
+
 template <class E, template <class> class ModelT>
 static hipError_t launch_forward_wave(LaunchArgs const& a) {
   constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
   int const grid = a.sa.stage ? stripe_grid(nblocks, STAGE_STRIPE) : ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
+  if constexpr (has_closed_form<ModelT<Dual>>::value) {
+    if (a.ms.closed_form) {
+      hipLaunchKernelGGL((k_forward_jacobian_wave_closed<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
+                         a.first, a.count, nblocks);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((k_forward_jacobian_wave<E, ModelT>), dim3(grid), dim3(JBLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
                      a.first, a.count, nblocks);
   return hipGetLastError();

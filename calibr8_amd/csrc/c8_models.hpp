@@ -203,6 +203,101 @@ template <class T, int DIM> struct SmallJ2Dim {
     }
     return path;
   }
+  // ---- the closed form of this model's local equations (3-D) ------------------------------------------------------------
+  // With linear hardening the return mapping has an explicit solution (radial return): from the trial stress
+  // s_tr = 2 mu (dev eps - pstrain_old), dgam = (|s_tr| - sqrt(2/3)(Y + K alpha_old)) / (2 mu + 2K/3), n = s_tr / |s_tr|,
+  // pstrain = pstrain_old + dgam n, alpha = alpha_old + sqrt(2/3) dgam -- the point the reference's Newton iteration
+  // (small_J2.cpp:122-173) converges to --, and the derivative of the stress through the local solve, which the
+  // reference obtains as dxi/dx = -(dC/dxi)^-1 dC/dx (evaluations.cpp:101-115), is the consistent tangent
+  // ds = a dev(sym d grad u) + b n (n : dev(sym d grad u)),  a = 2 mu theta,  b = 2 mu (1 - 2 mu / H - theta),
+  // theta = 1 - 2 mu dgam / |s_tr|, H = 2 mu + 2K/3 (elastic: a = 2 mu, b = 0).  The branch is the reference's test at the
+  // initial guess (f > tol || |f| < tol).  The forward wave kernel of hex8 uses it (c8_assemble_wave.hpp, CLOSED) in place
+  // of the Newton iteration, the inverse of dC/dxi and the AD passes of phase D; every other kernel, and this one when the
+  // caller asks for it (C8_KERNEL_WAVE_AD) or allows fewer than eight Newton iterations, runs the AD form above.
+  static constexpr bool HAS_CLOSED_FORM = (DIM == 3);
+  struct ClosedForm {
+    double xi[NLOC];   // converged local state
+    double F[13];      // flux values: Gu (xx xy xz yx yy yz zx zy zz), Vp (both ip sets), Gp
+    double a, b, n[9], trn3, inv_kappa, tau;
+  };
+  C8_HD static void closed_form(double const* prm, double const* q, double const* xi_old, double abs_tol, double h,
+                                double stab_mult, ClosedForm& cf) {
+    double const sqrt_23 = 0.81649658092772603273;
+    double const E = prm[0], nu = prm[1], K = prm[2], Y = prm[3];
+    double const mu = E / (2. * (1. + nu)), kappa = E / (3. * (1. - 2. * nu));
+    // q: grad u (row-major), p, grad p, u
+    double eps[9];
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i)
+      C8_UNROLL
+      for (int j = 0; j < 3; ++j) eps[3 * i + j] = 0.5 * (q[3 * i + j] + q[3 * j + i]);
+    double const tr = eps[0] + eps[4] + eps[8];
+    double const th = tr * (1. / 3.);
+    double const pold[9] = {xi_old[0], xi_old[1], xi_old[2], xi_old[1], xi_old[3], xi_old[4], xi_old[2], xi_old[4], xi_old[5]};
+    double st[9], ss = 0.;
+    C8_UNROLL
+    for (int k = 0; k < 9; ++k) {
+      double const dev = eps[k] - ((k == 0 || k == 4 || k == 8) ? th : 0.);
+      st[k] = (2. * mu) * (dev - pold[k]);
+      ss += st[k] * st[k];
+    }
+    double const smag = sqrt(ss);
+    double const alpha_old = xi_old[NSYM];
+    double const excess = smag - sqrt_23 * (Y + K * alpha_old);
+    double const f0 = excess / mu;
+    bool const plastic = f0 > abs_tol || fabs(f0) < abs_tol;
+    double theta = 1.;
+    cf.b = 0.;
+    C8_UNROLL
+    for (int k = 0; k < NLOC; ++k) cf.xi[k] = xi_old[k];
+    C8_UNROLL
+    for (int k = 0; k < 9; ++k) cf.n[k] = 0.;
+    cf.trn3 = 0.;
+    if (plastic) {
+      double const H = 2. * mu + (2. / 3.) * K;
+      double const dgam = excess / H;
+      double const inv = 1. / smag;
+      C8_UNROLL
+      for (int k = 0; k < 9; ++k) cf.n[k] = st[k] * inv;
+      cf.trn3 = (cf.n[0] + cf.n[4] + cf.n[8]) * (1. / 3.);
+      theta = 1. - (2. * mu) * dgam * inv;
+      cf.b = (2. * mu) * (1. - (2. * mu) / H - theta);
+      cf.xi[0] = xi_old[0] + dgam * cf.n[0]; cf.xi[1] = xi_old[1] + dgam * cf.n[1]; cf.xi[2] = xi_old[2] + dgam * cf.n[2];
+      cf.xi[3] = xi_old[3] + dgam * cf.n[4]; cf.xi[4] = xi_old[4] + dgam * cf.n[5]; cf.xi[5] = xi_old[5] + dgam * cf.n[8];
+      cf.xi[NSYM] = alpha_old + sqrt_23 * dgam;
+    }
+    cf.a = (2. * mu) * theta;
+    cf.inv_kappa = 1. / kappa;
+    cf.tau = (stab_mult * 0.5 * h * h) / mu;
+    double const p = q[9];
+    C8_UNROLL
+    for (int k = 0; k < 9; ++k) cf.F[k] = theta * st[k] - ((k == 0 || k == 4 || k == 8) ? p : 0.);
+    double const hydro = kappa * tr - prm[4] * prm[5] * E / (1. - 2. * nu);
+    cf.F[9] = -(hydro * cf.inv_kappa) + -(p * cf.inv_kappa);
+    cf.F[10] = -(cf.tau * q[10]); cf.F[11] = -(cf.tau * q[11]); cf.F[12] = -(cf.tau * q[12]);
+  }
+  // column c of d flux / d q (13 entries): c = 0..8 grad u (k, l), 9 p, 10..12 grad p, 13..15 u
+  C8_HD static void closed_form_column(ClosedForm const& cf, int c, double* col) {
+    // no run-time index into a local array anywhere (it would put the array into scratch memory): selects instead
+    bool const is_gu = c < 9, is_p = c == 9;
+    int const k = c / 3, l = c - 3 * k;
+    double const dkl = (is_gu && k == l) ? 1. : 0.;
+    double n_c = 0.;
+    C8_UNROLL
+    for (int m = 0; m < 9; ++m) n_c = (m == c) ? cf.n[m] : n_c;
+    double const nde = n_c - cf.trn3 * dkl;  // n : dev(sym E_kl), n symmetric
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i)
+      C8_UNROLL
+      for (int j = 0; j < 3; ++j) {
+        double const de = 0.5 * (((i == k && j == l) ? 1. : 0.) + ((i == l && j == k) ? 1. : 0.)) - ((i == j) ? dkl * (1. / 3.) : 0.);
+        double const gu = cf.a * de + cf.b * cf.n[3 * i + j] * nde;
+        col[3 * i + j] = is_gu ? gu : ((is_p && i == j) ? -1. : 0.);
+      }
+    col[9] = is_gu ? -dkl : (is_p ? -cf.inv_kappa : 0.);
+    C8_UNROLL
+    for (int m = 0; m < 3; ++m) col[10 + m] = (c == 10 + m) ? -cf.tau : 0.;
+  }
 };
 template <class T> struct SmallJ2 : SmallJ2Dim<T, 3> {};       // "small_J2" on a 3-D mesh
 template <class T> struct SmallJ2Plane : SmallJ2Dim<T, 2> {};  // "small_J2" on a 2-D mesh (notch2D_small_J2.yaml.in)

@@ -44,7 +44,7 @@ enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -
  * 64 neighbours.  If the stage cannot be allocated at the first Jacobian assembly, a context still in its default
  * mode switches to COLORED and says so in c8_last_error(). */
 enum { C8_SCATTER_ATOMIC = 0, C8_SCATTER_COLORED = 1, C8_SCATTER_GATHER = 2 };
-enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2 };
+enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2, C8_KERNEL_WAVE_AD = 3 };
 
 /* One mesh part (what Disc holds after loadMdsMesh, disc.cpp:31-39): all nodes that touch a
  * local element, local (GHOST) numbering. */
@@ -170,7 +170,12 @@ int c8_set_assign_mode(c8_ctx* ctx, int on);
  * every AD pass).  on = 0 frees the tables; results are the same either way. */
 int c8_set_shape_cache(c8_ctx* ctx, int on);
 /* Forward-assembly kernel: C8_KERNEL_SLOT = one lane group per element (any element type);
- * C8_KERNEL_WAVE = one wavefront per element (hex8); C8_KERNEL_AUTO picks WAVE where available. */
+ * C8_KERNEL_WAVE = one wavefront per element (hex8); C8_KERNEL_AUTO picks WAVE where available.  Where a model has a
+ * closed form of its local equations (small_J2 on 3-D meshes: radial return and consistent tangent), the forward WAVE
+ * kernel uses it in place of the local Newton iteration and the automatic-differentiation passes: the same converged
+ * state and Jacobian as the iterated form to within the local Newton tolerance (2e-13 measured).  C8_KERNEL_WAVE_AD keeps the iterated, automatically differentiated
+ * form in every kernel; it also runs whenever local_max_iters < 8, so that a local solve that cannot converge within
+ * the caller's budget still reports C8_LOCAL_SOLVE_FAILED as the reference does. */
 int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 /* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
  * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */

@@ -46,6 +46,14 @@ template <class Lane, int NDOF> struct CpuExec {
     cur = saved;
     return v;
   }
+  // get() of lane ^ 32 (GpuExec: a shuffle).  Sound here where no lane changes during an each() what its partner reads.
+  template <class F> double xor32(int lane, F get) {
+    int const saved = cur;
+    cur = lane ^ 32;
+    double const v = get(lane ^ 32);
+    cur = saved;
+    return v;
+  }
 };
 
 enum { K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
@@ -86,6 +94,7 @@ struct Call {
   int what;
   int staged;  // wave Jacobian kernels: staged (gather) assembly instead of direct adds
   int assign;  // staged assembly: the row sums assign A and b instead of adding (c8_set_assign_mode)
+  int closed;  // forward wave kernel: the model's closed form (what the library runs by default) instead of the AD / Newton form
   int nnodes;
   HostGraph const* graph;
   HostMesh const* mesh;
@@ -183,7 +192,12 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
   auto* ex = new CpuExec<WaveLane<ModelT>, 64>();
   auto one = [&](SystemArgs const& sa, int e) {
-    if (c.what == K_FORWARD_WAVE) forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
+    if (c.what == K_FORWARD_WAVE) {
+      if constexpr (has_closed_form<ModelT<Dual>>::value) {
+        if (c.closed) { forward_jacobian_wave_closed<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e); return; }
+      }
+      forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
+    }
     else adjoint_jacobian_wave<E, ModelT, PointQoi>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, sa, e);
   };
   if (c.staged) run_staged<E>(c, one);
@@ -315,6 +329,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   c.what = what & 0xff;
   c.staged = (what >> 8) & 1;
   c.assign = (what >> 9) & 1;
+  c.closed = (what >> 10) & 1;
   c.nnodes = nnodes;
   c.graph = &graph;
   c.mesh = &mesh;

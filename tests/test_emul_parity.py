@@ -53,6 +53,42 @@ def test_forward_jacobian_wave_kernel(model, params, eps):
     check_forward(orc, dut, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("staged", [False, True])
+@pytest.mark.parametrize("model,params,eps", CASES[:2])
+def test_forward_jacobian_wave_kernel_iterated_form(model, params, eps, staged):
+    # small_J2 has a closed form (radial return, consistent tangent) that the forward wave kernel runs by default
+    # (test_forward_jacobian_wave_kernel above); C8_KERNEL_WAVE_AD keeps the local Newton iteration and the AD passes
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.wave, dut.closed, dut.staged = True, False, staged
+    check_forward(orc, dut, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("params", [[1000.0, 0.25, 100.0, 2.0, 0.0, 0.0], [1000.0, 0.25, 0.0, 2.0, 0.0, 0.0],
+                                    [1000.0, 0.25, 5000.0, 0.5, 0.0, 0.0]])
+def test_closed_form_against_iterated_form(params):
+    # the two forms of the small_J2 kernel on the same two load steps (the second from a plastic state): same state,
+    # residual and Jacobian to the local Newton tolerance -- with hardening, perfectly plastic and with stiff hardening
+    import oracle_lib as ol
+    from meshes import prescribed_fields
+    from parity_cases import mesh_of
+    et, c, conn = mesh_of("hex8")
+    res = []
+    for closed in (True, False):
+        dut = em.Emul(et, c, conn, "small_J2", params)
+        dut.wave, dut.closed = True, closed
+        u1, p1 = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+        u0, p0 = np.zeros_like(u1), np.zeros_like(p1)
+        xi0, xi1, xi2 = dut.new_state(), dut.new_state(), dut.new_state()
+        l1, l2 = dut.new_linsys(), dut.new_linsys()
+        assert dut.forward_jacobian(u1, p1, u0, p0, xi0, xi1, l1) == 0
+        assert dut.forward_jacobian(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, l2) == 0
+        assert (xi2[:, :, 6] > xi1[:, :, 6]).any() and (xi1[:, :, 6] > 0).any() and (xi1[:, :, 6] == 0).any()
+        res.append([xi1, xi2] + [l.b[i] for l in (l1, l2) for i in range(2)] +
+                   [l.A[i][j] for l in (l1, l2) for i in range(2) for j in range(2)])
+    for a, b in zip(*res):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+
+
 @pytest.mark.parametrize("model,params,eps", CASES)
 def test_adjoint_chain_wave_kernel(model, params, eps):
     orc, dut, c = make_pair(factory, "hex8", model, params)

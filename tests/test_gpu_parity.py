@@ -309,6 +309,52 @@ def test_local_solve_failure_returns_minus_one():
     assert gpu.forward_jacobian(ue, pe, z, zp, gpu.new_state(), gpu.new_state(), gpu.new_linsys()) == 0
 
 
+@pytest.mark.parametrize("scatter", ["gather", "colored", "atomic"])
+@pytest.mark.parametrize("model,params,eps", CASES[:2])
+def test_forward_jacobian_iterated_form_hex8(model, params, eps, scatter):
+    # small_J2 on hex8 runs its closed form by default (every other hex8 small_J2 test of this file); C8_KERNEL_WAVE_AD
+    # keeps the local Newton iteration and the AD passes in the same kernel
+    orc, gpu, c = make_pair(factory(scatter, "wave_ad"), "hex8", model, params)
+    check_forward(orc, gpu, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("params", [[1000.0, 0.25, 100.0, 2.0, 0.0, 0.0], [1000.0, 0.25, 0.0, 2.0, 0.0, 0.0],
+                                    [1000.0, 0.25, 5000.0, 0.5, 0.0, 0.0]])
+def test_closed_form_against_iterated_form(params):
+    # both forms of the kernel on two load steps of a 12^3 brick (the second from a plastic state): same state, residual
+    # and Jacobian to the local Newton tolerance; then the variant switch back to the default
+    from gpu_backend import GpuBackend
+    c, conn = hex_mesh((12, 12, 12))
+    gpu = GpuBackend(ol.HEX8, c, conn, "small_J2", params, scatter="gather")
+    u1, p1 = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    u0, p0 = np.zeros_like(u1), np.zeros_like(p1)
+
+    def run(kernel):
+        gpu.asm.set_kernel(kernel)
+        xi0, xi1, xi2 = gpu.new_state(), gpu.new_state(), gpu.new_state()
+        l1, l2 = gpu.new_linsys(), gpu.new_linsys()
+        assert gpu.forward_jacobian(u1, p1, u0, p0, xi0, xi1, l1) == 0
+        assert gpu.forward_jacobian(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, l2) == 0
+        assert (xi2[:, :, 6] > xi1[:, :, 6]).any() and (xi1[:, :, 6] > 0).any() and (xi1[:, :, 6] == 0).any()
+        return [xi1, xi2] + [l.b[i] for l in (l1, l2) for i in range(2)] + \
+               [l.A[i][j] for l in (l1, l2) for i in range(2) for j in range(2)]
+
+    closed, iterated, again = run("auto"), run("wave_ad"), run("wave")
+    for a, b, a2 in zip(closed, iterated, again):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+        assert np.array_equal(a, a2)  # staged assembly: bitwise reproducible, and "wave" is the default form again
+
+
+def test_iterated_form_needs_the_wave_kernel():
+    from calibr8_amd import C8Error
+    from gpu_backend import GpuBackend
+    from parity_cases import mesh_of
+    et, c, conn = mesh_of("tet4")
+    gpu = GpuBackend(et, c, conn, "small_J2", J2)
+    with pytest.raises(C8Error):
+        gpu.asm.set_kernel("wave_ad")
+
+
 def test_cube_elastic_pin_through_gpu():
     # reference regression primal/cube_elastic.yaml.in:40-41 reproduced with the HIP assembly
     from fe_driver import Dbc, Primal

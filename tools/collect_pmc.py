@@ -64,10 +64,13 @@ def main():
     ba = args.bench_args
     opt = lambda name, default: ba[ba.index(name) + 1] if name in ba else default
     scatter, kernel = opt("--scatter", "gather"), opt("--kernel", "auto")
-    out["config"] = {"edge": int(opt("--edge", 100)), "scatter": scatter, "kernel": "slot" if kernel == "slot" else "wave"}
+    kkey = kernel if kernel in ("slot", "wave_ad") else "wave"
+    out["config"] = {"edge": int(opt("--edge", 100)), "scatter": scatter, "kernel": kkey}
     out["build_id"] = info.split()[0].split("=")[1]
     out["library_build"] = info
+    # bench.py also times the iterated form of the kernel beside the headline: keep the kernel of the configuration named
     fwd = [k for k in out["per_launch_mean"] if "k_forward_jacobian" in k and "SmallJ2" in k]
+    fwd = [k for k in fwd if ("_closed" in k) == (kkey == "wave")] or fwd
     rows = [k for k in out["per_launch_mean"] if "k_gather_rows" in k] if scatter == "gather" else []
     out["launches_per_assembly"] = fwd[:1] + rows[:1]
     ncol = {"colored": 8}.get(scatter, 1)  # per_launch_mean of a colour-batched assembly is the mean over its launches
