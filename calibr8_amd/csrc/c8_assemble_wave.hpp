@@ -108,7 +108,7 @@ template <class E, int NL, bool ADJ = true, bool PREV = true, bool NOSOLVE = fal
   double N[E::NP0][E::NN];
   double dN[E::NP0][E::NN][3];
   double wdv[E::NP0];
-  double M[NOSOLVE ? 1 : E::NP0][NLP][NLP + 1];   // dC/dxi per point
+  double M[NOSOLVE ? 1 : E::NP0][NOSOLVE ? 1 : NLP][NLP + 1];   // dC/dxi per point
   double q[E::NP0][WQ];             // interpolated values
   double qprev[PREV ? E::NP0 : 1][9];  // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
@@ -607,32 +607,46 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   }
 
   }  // !CLOSED
+  if constexpr (CLOSED) {
+    // the model's closed form (Model::closed_form) once per point, on the first lane of the point's eight: it reads the
+    // point quantities and the previous state, stores the converged state and the weighted fluxes, and leaves what the
+    // tangent columns need IN PLACE OF the point quantities (sh.q[pt][0 .. NT-1]; nothing reads q afterwards)
+    static_assert(Model::ClosedForm::NT <= WQ, "the tangent data take the place of the point quantities");
+    ex.each([&](int lane) {
+      int const pt = lane >> 3, d = lane & 7;
+      if (d != 0) return;
+      int const es = mt.elem_set ? mt.elem_set[e] : 0;
+      typename Model::ClosedForm cf;
+      Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, sh.q[pt], sh.xip[pt], ms.abs_tol, sh.h, ms.stab_mult, cf);
+      size_t const q0 = ((size_t)e * E::NP0 + pt) * NL;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) fa.xi[q0 + j] = cf.xi[j];
+      double const w = sh.wdv[pt];
+      double* Fp = sh.F[pt];
+      C8_UNROLL
+      for (int rr = 0; rr < WF; ++rr) Fp[rr] = w * cf.F[rr];
+      C8_UNROLL
+      for (int i = 0; i < Model::ClosedForm::NT; ++i) sh.q[pt][i] = cf.t[i];
+    });
+    ex.sync();
+  }
   C8_STAMP(3);
   // ---- phases D and P, 4 points per pass -------------------------------------------------------------
   for (int t = 0; t < 2; ++t) {
     if constexpr (CLOSED) {
-      // the model's closed form (Model::closed_form): lane (ql, c) solves point 4 t + ql (all sixteen lanes of a point the
-      // same few dozen operations) and writes column c of its d flux / d q; lane c = 0 also stores the state and the fluxes
+      // lane (ql, c) writes column c of d flux / d q of point 4 t + ql from the point's tangent data
       ex.each([&](int lane) {
         int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
-        int const es = mt.elem_set ? mt.elem_set[e] : 0;
-        typename Model::ClosedForm cf;
-        Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, sh.q[pt], sh.xip[pt], ms.abs_tol, sh.h, ms.stab_mult, cf);
+        double tn[Model::ClosedForm::NT];
+        C8_UNROLL
+        for (int i = 0; i < Model::ClosedForm::NT; ++i) tn[i] = sh.q[pt][i];
         double col[WF];
-        Model::closed_form_column(cf, c, col);
+        Model::closed_form_column(tn, c, col);
         double const w = sh.wdv[pt];
         constexpr int LD = WQ + 1;
         double* Dc = &sh.D[ql][0][c];
         C8_UNROLL
         for (int rr = 0; rr < WF; ++rr) Dc[rr * LD] = w * col[rr];
-        if (c == 0) {
-          size_t const q0 = ((size_t)e * E::NP0 + pt) * NL;
-          C8_UNROLL
-          for (int j = 0; j < NL; ++j) { fa.xi[q0 + j] = cf.xi[j]; sh.xi[pt][j] = cf.xi[j]; }
-          double* Fp = sh.F[pt];
-          C8_UNROLL
-          for (int rr = 0; rr < WF; ++rr) Fp[rr] = w * cf.F[rr];
-        }
       });
     } else
     ex.each([&](int lane) {

@@ -216,15 +216,18 @@ template <class T, int DIM> struct SmallJ2Dim {
   // caller asks for it (C8_KERNEL_WAVE_AD) or allows fewer than eight Newton iterations, runs the AD form above.
   static constexpr bool HAS_CLOSED_FORM = (DIM == 3);
   struct ClosedForm {
+    static constexpr int NT = 14;
     double xi[NLOC];   // converged local state
     double F[13];      // flux values: Gu (xx xy xz yx yy yz zx zy zz), Vp (both ip sets), Gp
-    double a, b, n[9], trn3, inv_kappa, tau;
+    double t[NT];      // what the tangent columns need: a, b, tr(n)/3, 1/kappa, tau, n (9)
   };
+  // once per point (the kernel runs it on one lane per point and hands t to the lanes that write the columns)
   C8_HD static void closed_form(double const* prm, double const* q, double const* xi_old, double abs_tol, double h,
                                 double stab_mult, ClosedForm& cf) {
     double const sqrt_23 = 0.81649658092772603273;
     double const E = prm[0], nu = prm[1], K = prm[2], Y = prm[3];
-    double const mu = E / (2. * (1. + nu)), kappa = E / (3. * (1. - 2. * nu));
+    double const mu = E * c8_rcp(2. * (1. + nu)), kappa = E * c8_rcp(3. * (1. - 2. * nu));
+    double const inv_mu = c8_rcp(mu);
     // q: grad u (row-major), p, grad p, u
     double eps[9];
     C8_UNROLL
@@ -244,59 +247,64 @@ template <class T, int DIM> struct SmallJ2Dim {
     double const smag = sqrt(ss);
     double const alpha_old = xi_old[NSYM];
     double const excess = smag - sqrt_23 * (Y + K * alpha_old);
-    double const f0 = excess / mu;
+    double const f0 = excess * inv_mu;
     bool const plastic = f0 > abs_tol || fabs(f0) < abs_tol;
     double theta = 1.;
-    cf.b = 0.;
+    double* n = cf.t + 5;
+    cf.t[1] = 0.;
     C8_UNROLL
     for (int k = 0; k < NLOC; ++k) cf.xi[k] = xi_old[k];
     C8_UNROLL
-    for (int k = 0; k < 9; ++k) cf.n[k] = 0.;
-    cf.trn3 = 0.;
+    for (int k = 0; k < 9; ++k) n[k] = 0.;
+    cf.t[2] = 0.;
     if (plastic) {
-      double const H = 2. * mu + (2. / 3.) * K;
-      double const dgam = excess / H;
-      double const inv = 1. / smag;
+      double const inv_H = c8_rcp(2. * mu + (2. / 3.) * K);
+      double const dgam = excess * inv_H;
+      double const inv = c8_rcp(smag);
       C8_UNROLL
-      for (int k = 0; k < 9; ++k) cf.n[k] = st[k] * inv;
-      cf.trn3 = (cf.n[0] + cf.n[4] + cf.n[8]) * (1. / 3.);
+      for (int k = 0; k < 9; ++k) n[k] = st[k] * inv;
+      cf.t[2] = (n[0] + n[4] + n[8]) * (1. / 3.);
       theta = 1. - (2. * mu) * dgam * inv;
-      cf.b = (2. * mu) * (1. - (2. * mu) / H - theta);
-      cf.xi[0] = xi_old[0] + dgam * cf.n[0]; cf.xi[1] = xi_old[1] + dgam * cf.n[1]; cf.xi[2] = xi_old[2] + dgam * cf.n[2];
-      cf.xi[3] = xi_old[3] + dgam * cf.n[4]; cf.xi[4] = xi_old[4] + dgam * cf.n[5]; cf.xi[5] = xi_old[5] + dgam * cf.n[8];
+      cf.t[1] = (2. * mu) * (1. - (2. * mu) * inv_H - theta);
+      cf.xi[0] = xi_old[0] + dgam * n[0]; cf.xi[1] = xi_old[1] + dgam * n[1]; cf.xi[2] = xi_old[2] + dgam * n[2];
+      cf.xi[3] = xi_old[3] + dgam * n[4]; cf.xi[4] = xi_old[4] + dgam * n[5]; cf.xi[5] = xi_old[5] + dgam * n[8];
       cf.xi[NSYM] = alpha_old + sqrt_23 * dgam;
     }
-    cf.a = (2. * mu) * theta;
-    cf.inv_kappa = 1. / kappa;
-    cf.tau = (stab_mult * 0.5 * h * h) / mu;
+    cf.t[0] = (2. * mu) * theta;
+    double const inv_kappa = c8_rcp(kappa);
+    double const tau = (stab_mult * 0.5 * h * h) * inv_mu;
+    cf.t[3] = inv_kappa;
+    cf.t[4] = tau;
     double const p = q[9];
     C8_UNROLL
     for (int k = 0; k < 9; ++k) cf.F[k] = theta * st[k] - ((k == 0 || k == 4 || k == 8) ? p : 0.);
-    double const hydro = kappa * tr - prm[4] * prm[5] * E / (1. - 2. * nu);
-    cf.F[9] = -(hydro * cf.inv_kappa) + -(p * cf.inv_kappa);
-    cf.F[10] = -(cf.tau * q[10]); cf.F[11] = -(cf.tau * q[11]); cf.F[12] = -(cf.tau * q[12]);
+    double const hydro = kappa * tr - prm[4] * prm[5] * E * c8_rcp(1. - 2. * nu);
+    cf.F[9] = -(hydro * inv_kappa) + -(p * inv_kappa);
+    cf.F[10] = -(tau * q[10]); cf.F[11] = -(tau * q[11]); cf.F[12] = -(tau * q[12]);
   }
   // column c of d flux / d q (13 entries): c = 0..8 grad u (k, l), 9 p, 10..12 grad p, 13..15 u
-  C8_HD static void closed_form_column(ClosedForm const& cf, int c, double* col) {
+  C8_HD static void closed_form_column(double const* t, int c, double* col) {
     // no run-time index into a local array anywhere (it would put the array into scratch memory): selects instead
+    double const a = t[0], b = t[1], trn3 = t[2], inv_kappa = t[3], tau = t[4];
+    double const* n = t + 5;
     bool const is_gu = c < 9, is_p = c == 9;
     int const k = c / 3, l = c - 3 * k;
     double const dkl = (is_gu && k == l) ? 1. : 0.;
     double n_c = 0.;
     C8_UNROLL
-    for (int m = 0; m < 9; ++m) n_c = (m == c) ? cf.n[m] : n_c;
-    double const nde = n_c - cf.trn3 * dkl;  // n : dev(sym E_kl), n symmetric
+    for (int m = 0; m < 9; ++m) n_c = (m == c) ? n[m] : n_c;
+    double const nde = n_c - trn3 * dkl;  // n : dev(sym E_kl), n symmetric
     C8_UNROLL
     for (int i = 0; i < 3; ++i)
       C8_UNROLL
       for (int j = 0; j < 3; ++j) {
         double const de = 0.5 * (((i == k && j == l) ? 1. : 0.) + ((i == l && j == k) ? 1. : 0.)) - ((i == j) ? dkl * (1. / 3.) : 0.);
-        double const gu = cf.a * de + cf.b * cf.n[3 * i + j] * nde;
+        double const gu = a * de + b * n[3 * i + j] * nde;
         col[3 * i + j] = is_gu ? gu : ((is_p && i == j) ? -1. : 0.);
       }
-    col[9] = is_gu ? -dkl : (is_p ? -cf.inv_kappa : 0.);
+    col[9] = is_gu ? -dkl : (is_p ? -inv_kappa : 0.);
     C8_UNROLL
-    for (int m = 0; m < 3; ++m) col[10 + m] = (c == 10 + m) ? -cf.tau : 0.;
+    for (int m = 0; m < 3; ++m) col[10 + m] = (c == 10 + m) ? -tau : 0.;
   }
 };
 template <class T> struct SmallJ2 : SmallJ2Dim<T, 3> {};       // "small_J2" on a 3-D mesh
