@@ -21,9 +21,6 @@
 // sets (hex8): the two ip sets are fused by adding the pressure-mass flux to V_p.
 #pragma once
 // Diagnostic build only (-DC8_STAMPS, tools/stamp_phases.py): s_memtime stamps at phase boundaries.
-#ifndef C8_CLOSED_P2
-#define C8_CLOSED_P2 1  // timing switch: 0 = the closed-form kernel keeps the (flux group, column) lanes of phase P
-#endif
 #ifdef C8_STAMPS
 #define C8_STAMP(i) ex.stamp(sa, e, i)
 #else
@@ -113,7 +110,7 @@ template <class E, int NL, bool ADJ = true, bool PREV = true, bool NOSOLVE = fal
   double qprev[PREV ? E::NP0 : 1][9];  // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
   double xip[E::NP0][NLP];          // previous local state
-  double D[4][WF][WQ + 1];          // dflux/dq of the 4 points of a pass
+  double D[NOSOLVE ? 1 : 4][WF][WQ + 1];  // dflux/dq of the 4 points of a pass
   double F[E::NP0][WF];             // flux values
   double gh[ADJ ? E::NP0 : 1][NLP]; // adjoint: local history g at each point
   double rq[ADJ ? 4 : 1][WQ + 1];   // adjoint: -dJ/dq + (dxi/dq)^T g of the 4 points of a pass
@@ -631,24 +628,49 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     ex.sync();
   }
   C8_STAMP(3);
-  // ---- phases D and P, 4 points per pass -------------------------------------------------------------
-  for (int t = 0; t < 2; ++t) {
-    if constexpr (CLOSED) {
-      // lane (ql, c) writes column c of d flux / d q of point 4 t + ql from the point's tangent data
-      ex.each([&](int lane) {
-        int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
+  if constexpr (CLOSED) {
+    // ---- phase P of the closed-form kernel: lane = (point half hf, column b), no D in LDS.  The model gives (D B)[.][b],
+    //      the 13 flux derivatives with respect to this lane's element unknown, directly from the point's tangent data and
+    //      the column node's shape entries (Model::closed_form_flux_column); the lane then takes ALL 32 rows of its column
+    //      for the four points of its half, so the eight nodes' shape entries (the same for every lane of a half) are read
+    //      once per point for 13 products.  J holds the rows (n, u_0), (n, u_1) (flux group 0), J1 the rows (n, u_2),
+    //      (n, p) (group 1), in the order the scatter expects; the halves exchange their partial sums below.
+    static_assert(!ADJOINT && !Mechanics::USES_U, "the closed-form kernel is the forward assembly of a weak form without u terms");
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      int const b = lane & 31, hf = lane >> 5;
+      bool const bu = b < 3 * E::NN;
+      int const m = bu ? b / 3 : b - 3 * E::NN;
+      int const k = bu ? b - 3 * m : 3;
+      double const ek[3] = {k == 0 ? 1. : 0., k == 1 ? 1. : 0., k == 2 ? 1. : 0.};
+      double const isp = bu ? 0. : 1.;
+      int const cg = bu ? 3 * k : 10;
+      C8_NOUNROLL
+      for (int q4 = 0; q4 < 4; ++q4) {
+        int const pt = 4 * hf + q4;
+        double const w = sh.wdv[pt];
+        double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
+        double const g[3] = {w * b0, w * b1, w * b2};
         double tn[Model::ClosedForm::NT];
         C8_UNROLL
         for (int i = 0; i < Model::ClosedForm::NT; ++i) tn[i] = sh.q[pt][i];
-        double col[WF];
-        Model::closed_form_column(tn, c, col);
-        double const w = sh.wdv[pt];
-        constexpr int LD = WQ + 1;
-        double* Dc = &sh.D[ql][0][c];
+        double db[WF];
+        Model::closed_form_flux_column(tn, ek, isp, g, w * bN, db);
         C8_UNROLL
-        for (int rr = 0; rr < WF; ++rr) Dc[rr * LD] = w * col[rr];
-      });
-    } else
+        for (int n = 0; n < E::NN; ++n) {
+          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+          r.J[2 * n] += a0 * db[0] + a1 * db[1] + a2 * db[2];
+          r.J[2 * n + 1] += a0 * db[3] + a1 * db[4] + a2 * db[5];
+          r.J1[2 * n] += a0 * db[6] + a1 * db[7] + a2 * db[8];
+          r.J1[2 * n + 1] += a0 * db[10] + a1 * db[11] + a2 * db[12] + aN * db[9];
+        }
+        double const* Fp = sh.F[pt];
+        r.R += Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * (isp * bN);
+      }
+    });
+  } else
+  // ---- phases D and P, 4 points per pass -------------------------------------------------------------
+  for (int t = 0; t < 2; ++t) {
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
       int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
@@ -718,47 +740,6 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     //   g = 1: entries (node n, u_2) from flux rows 6..8 and (n, p)   from flux rows 9..12
     // Both halves run one instruction stream: entry E0 takes rows r0..r0+2, entry E1 rows r1..r1+2 plus
     // row 9 with weight zf (zero for g = 0).  J[2n] = E0 of node n, J[2n+1] = E1 of node n.
-    if constexpr (CLOSED && !ADJOINT && C8_CLOSED_P2) {
-    // phase P of the closed-form kernel: lane = (point half hf, column b).  Each half takes two of the pass's four points
-    // and ALL 32 rows of column b, so the eight nodes' shape entries (the same for every lane of a half) are read once
-    // per point for 13 products instead of 7: a third fewer LDS reads, which bound this phase.  The
-    // accumulators are J (rows (n, u_0), (n, u_1): flux group 0) and J1 (rows (n, u_2), (n, p): flux group 1); the two
-    // halves' partial sums are exchanged once per element, after the last pass.
-    ex.each([&](int lane) {
-      auto& r = ex.lane(lane);
-      int const b = lane & 31, hf = lane >> 5;
-      bool const bu = b < 3 * E::NN;
-      int const m = bu ? b / 3 : b - 3 * E::NN;
-      int const k = bu ? b - 3 * m : 0;
-      int const cg = bu ? 3 * k : 10;
-      int const cv = bu ? 13 + k : 9;
-      bool const has_cv = Mechanics::USES_U || !bu;
-      int const cvl = has_cv ? cv : 9;
-      C8_NOUNROLL
-      for (int q2 = 0; q2 < 2; ++q2) {
-        int const ql = 2 * hf + q2, pt = 4 * t + ql;
-        double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
-        double const bNv = has_cv ? bN : 0.;
-        double const bNp = bu ? 0. : bN;
-        double db[WF];
-        C8_UNROLL
-        for (int rr = 0; rr < WF; ++rr) {
-          double const* Dr = sh.D[ql][rr];
-          db[rr] = Dr[cg] * b0 + Dr[cg + 1] * b1 + Dr[cg + 2] * b2 + Dr[cvl] * bNv;
-        }
-        C8_UNROLL
-        for (int n = 0; n < E::NN; ++n) {
-          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
-          r.J[2 * n] += a0 * db[0] + a1 * db[1] + a2 * db[2];
-          r.J[2 * n + 1] += a0 * db[3] + a1 * db[4] + a2 * db[5];
-          r.J1[2 * n] += a0 * db[6] + a1 * db[7] + a2 * db[8];
-          r.J1[2 * n + 1] += a0 * db[10] + a1 * db[11] + a2 * db[12] + aN * db[9];
-        }
-        double const* Fp = sh.F[pt];
-        r.R += Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * bNp;
-      }
-    });
-    } else
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
       int const b = lane & 31, g = lane >> 5;
@@ -820,7 +801,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     ex.sync();
     C8_STAMP(5 + 2 * t);
   }
-  if constexpr (CLOSED && !ADJOINT && C8_CLOSED_P2) {
+  if constexpr (CLOSED) {
     // the halves exchange their partial sums: half 0 completes group 0 (J), half 1 completes group 1 (J1) and moves it
     // into J, which the scatter reads
     ex.each([&](int lane) {

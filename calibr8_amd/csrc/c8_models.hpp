@@ -282,29 +282,37 @@ template <class T, int DIM> struct SmallJ2Dim {
     cf.F[9] = -(hydro * inv_kappa) + -(p * inv_kappa);
     cf.F[10] = -(tau * q[10]); cf.F[11] = -(tau * q[11]); cf.F[12] = -(tau * q[12]);
   }
-  // column c of d flux / d q (13 entries): c = 0..8 grad u (k, l), 9 p, 10..12 grad p, 13..15 u
-  C8_HD static void closed_form_column(double const* t, int c, double* col) {
-    // no run-time index into a local array anywhere (it would put the array into scratch memory): selects instead
+  // (d flux / d q)(d q / d x_b) for one element unknown x_b, 13 entries: x_b = u_k of a node (ek = e_k, isp = 0) or p of a
+  // node (ek = 0, isp = 1); g = dN/dx and N = the shape value of that node at the point (a weight may ride on both).
+  // With the consistent tangent d s_ij / d eps_kl = a (sym_ijkl - delta_ij delta_kl / 3) + b n_ij (n_kl - tr(n)/3 delta_kl):
+  //   rows 0..8   a (1/2 (ek_i g_j + g_i ek_j) - delta_ij g_k / 3) + b n_ij (n_k. g - tr(n)/3 g_k) - delta_ij isp N
+  //   row  9      -g_k - isp N / kappa          rows 10..12   -isp tau g_l
+  // One instruction stream for all columns: no selects, the flags are factors.
+  C8_HD static void closed_form_flux_column(double const* t, double const* ek, double isp, double const* g, double N, double* db) {
     double const a = t[0], b = t[1], trn3 = t[2], inv_kappa = t[3], tau = t[4];
     double const* n = t + 5;
-    bool const is_gu = c < 9, is_p = c == 9;
-    int const k = c / 3, l = c - 3 * k;
-    double const dkl = (is_gu && k == l) ? 1. : 0.;
-    double n_c = 0.;
+    double const gk = ek[0] * g[0] + ek[1] * g[1] + ek[2] * g[2];
+    double ng[3];  // n g
     C8_UNROLL
-    for (int m = 0; m < 9; ++m) n_c = (m == c) ? n[m] : n_c;
-    double const nde = n_c - trn3 * dkl;  // n : dev(sym E_kl), n symmetric
+    for (int i = 0; i < 3; ++i) ng[i] = n[3 * i] * g[0] + n[3 * i + 1] * g[1] + n[3 * i + 2] * g[2];
+    double const nkg = ek[0] * ng[0] + ek[1] * ng[1] + ek[2] * ng[2];  // n symmetric: (n g)_k = n_k. g
+    double const bnk = b * (nkg - trn3 * gk);
+    double const Np = isp * N;
+    double const diag = a * gk * (1. / 3.) + Np;
+    double const ha = 0.5 * a;
+    double hg[3], hek[3];
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i) { hg[i] = ha * g[i]; hek[i] = ek[i]; }
     C8_UNROLL
     for (int i = 0; i < 3; ++i)
       C8_UNROLL
       for (int j = 0; j < 3; ++j) {
-        double const de = 0.5 * (((i == k && j == l) ? 1. : 0.) + ((i == l && j == k) ? 1. : 0.)) - ((i == j) ? dkl * (1. / 3.) : 0.);
-        double const gu = a * de + b * n[3 * i + j] * nde;
-        col[3 * i + j] = is_gu ? gu : ((is_p && i == j) ? -1. : 0.);
+        double const v = hek[i] * hg[j] + hg[i] * hek[j] + n[3 * i + j] * bnk;
+        db[3 * i + j] = (i == j) ? v - diag : v;
       }
-    col[9] = is_gu ? -dkl : (is_p ? -inv_kappa : 0.);
-    C8_UNROLL
-    for (int m = 0; m < 3; ++m) col[10 + m] = (c == 10 + m) ? -tau : 0.;
+    db[9] = -gk - Np * inv_kappa;
+    double const tp = isp * tau;
+    db[10] = -(tp * g[0]); db[11] = -(tp * g[1]); db[12] = -(tp * g[2]);
   }
 };
 template <class T> struct SmallJ2 : SmallJ2Dim<T, 3> {};       // "small_J2" on a 3-D mesh
