@@ -183,6 +183,10 @@ class Assembler:
         """scatter='gather': smallest chunk of elements staged at a time (default 8192)"""
         _l.check(self.L.c8_set_stage_chunk(self.h, int(min_chunk)))
 
+    def set_stage_overlap(self, on):
+        """scatter='gather' in several chunks: the row sums of a chunk beside the assembly of the next one (second stream)"""
+        _l.check(self.L.c8_set_stage_overlap(self.h, int(bool(on))))
+
     def set_kernel(self, variant):
         """'auto' | 'slot' (one lane group per element) | 'wave' (one wavefront per hex8 element) | 'wave_ad' (the same with the
         iterated, automatically differentiated local solve also where a model has a closed form)"""

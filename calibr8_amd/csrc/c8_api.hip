@@ -210,6 +210,9 @@ int c8_set_shape_cache(c8_ctx* c, int on) {
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
   stage_release(c);
+  for (hipEvent_t e : c->ev_asm) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_sum) (void)hipEventDestroy(e);
+  if (c->sum_stream) (void)hipStreamDestroy(c->sum_stream);
   void* bufs[] = {c->d_shape, c->d_cal_faces, c->d_cal_S, c->d_nodeelem_ptr, c->d_nodeelem, c->d_nodeadj, c->d_scalar, c->d_xi_saved, c->d_work[0], c->d_work[1], c->d_work[2], c->d_work[3], c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, c->d_order, c->d_params, c->d_active, c->d_status};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
@@ -300,6 +303,13 @@ int c8_set_stage_chunk(c8_ctx* c, int min_chunk) {
   C8_HIP(hipDeviceSynchronize());
   stage_release(c);  // the plan is rebuilt at the next staged assembly
   c->stage_min_chunk = min_chunk;
+  return C8_OK;
+}
+int c8_set_stage_overlap(c8_ctx* c, int on) {
+  if (!c) return fail(C8_ERR_ARG, "c8_set_stage_overlap: null ctx");
+  if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_stage_overlap: a staged assembly is waiting for c8_gather_finish");
+  C8_HIP(hipDeviceSynchronize());
+  c->stage_overlap = on ? 1 : 0;
   return C8_OK;
 }
 int c8_set_assign_mode(c8_ctx* c, int on) {
@@ -416,6 +426,34 @@ static int run_staged(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs c
     if (c->async) return C8_OK;
     return c8_status(c);
   }
+  if (c->stage_overlap && pl.nchunks > 1) {
+    // the row sums of chunk k (bound by HBM) run on a second stream beside the assembly of chunk k + 1 (bound by
+    // instruction issue).  Order: row sums k after assembly k; assembly k after row sums k - 2, whose ring slot it
+    // overwrites (row sums k read the slots of chunks k - 1 and k); the caller's stream continues after the last row sums.
+    if (!c->sum_stream) {  // highest priority: the row-sum waves take the slots the assembly waves free as they retire
+      int lo = 0, hi = 0;
+      C8_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      char const* pr = getenv("C8_SUM_STREAM_PRIORITY");
+      C8_HIP(hipStreamCreateWithPriority(&c->sum_stream, hipStreamNonBlocking, pr ? atoi(pr) : hi));
+    }
+    while ((int)c->ev_asm.size() < pl.nchunks) {
+      hipEvent_t e0, e1;
+      C8_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      C8_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      c->ev_asm.push_back(e0);
+      c->ev_sum.push_back(e1);
+    }
+    for (int k = 0; k < pl.nchunks; ++k) {
+      if (k >= 2) C8_HIP(hipStreamWaitEvent(c->stream, c->ev_sum[k - 2], 0));
+      LaunchArgs a{tables(c, false), c->ms, fa, aa, sa, k * pl.chunk, std::min(pl.chunk, c->mesh.nelems - k * pl.chunk), c->stream};
+      C8_HIP(fn(a));
+      C8_HIP(hipEventRecord(c->ev_asm[k], c->stream));
+      C8_HIP(hipStreamWaitEvent(c->sum_stream, c->ev_asm[k], 0));
+      C8_HIP(c->ks.gather_rows(ga, pl.node_off[k], pl.node_off[k + 1] - pl.node_off[k], c->graph.max_degree, c->sum_stream));
+      C8_HIP(hipEventRecord(c->ev_sum[k], c->sum_stream));
+    }
+    C8_HIP(hipStreamWaitEvent(c->stream, c->ev_sum[pl.nchunks - 1], 0));
+  } else
   for (int k = 0; k < pl.nchunks; ++k) {
     LaunchArgs a{tables(c, false), c->ms, fa, aa, sa, k * pl.chunk, std::min(pl.chunk, c->mesh.nelems - k * pl.chunk), c->stream};
     C8_HIP(fn(a));

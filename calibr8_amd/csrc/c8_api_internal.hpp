@@ -43,6 +43,11 @@ struct c8_ctx {
   int32_t* d_node_order = nullptr;
   c8::StagePlan plan;                 // staged assembly: chunks, ring, node order
   int stage_min_chunk = 0;            // 0: automatic (c8_api.hip: stage_setup)
+  // staged assembly with the row sums of chunk k beside the assembly of chunk k + 1 (c8_set_stage_overlap): the row-sum
+  // launches go to sum_stream, events order the two streams both ways
+  int stage_overlap = 0;
+  hipStream_t sum_stream = nullptr;
+  std::vector<hipEvent_t> ev_asm, ev_sum;
   // staged assembly in two parts (c8_set_gather_early_nodes): the rows of nodes [early_begin, early_end) are summed by
   // the assembly call, the other rows by c8_gather_finish
   int early_begin = 0, early_end = 0, early_count = 0;

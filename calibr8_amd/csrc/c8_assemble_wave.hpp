@@ -106,7 +106,10 @@ template <class E, int NL, bool ADJ = true, bool PREV = true, bool NOSOLVE = fal
   double dN[E::NP0][E::NN][3];
   double wdv[E::NP0];
   double M[NOSOLVE ? 1 : E::NP0][NOSOLVE ? 1 : NLP][NLP + 1];   // dC/dxi per point
-  double q[E::NP0][WQ];             // interpolated values
+  alignas(16) double q[E::NP0][WQ]; // interpolated values
+  // closed-form forward kernel: (dN/dx_0, dN/dx_1, dN/dx_2, N) of every (point, node) side by side, so that phase P reads
+  // a node's four shape entries with two 16-byte LDS loads
+  alignas(16) double G4[NOSOLVE ? E::NP0 : 1][NOSOLVE ? E::NN : 1][4];
   double qprev[PREV ? E::NP0 : 1][9];  // grad_u at the previous step (finite deformation)
   double xi[E::NP0][NLP];           // converged local state
   double xip[E::NP0][NLP];          // previous local state
@@ -468,6 +471,12 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       sh.xip[pt][d] = r.xip_pre;
       sh.xi[pt][d] = r.xi_pre;
     }
+    if constexpr (CLOSED) {  // lane = (point, node d)
+      sh.G4[pt][d][0] = sh.dN[pt][d][0];
+      sh.G4[pt][d][1] = sh.dN[pt][d][1];
+      sh.G4[pt][d][2] = sh.dN[pt][d][2];
+      sh.G4[pt][d][3] = sh.N[pt][d];
+    }
   });
   ex.sync();
 
@@ -649,7 +658,8 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       for (int q4 = 0; q4 < 4; ++q4) {
         int const pt = 4 * hf + q4;
         double const w = sh.wdv[pt];
-        double const bN = sh.N[pt][m], b0 = sh.dN[pt][m][0], b1 = sh.dN[pt][m][1], b2 = sh.dN[pt][m][2];
+        double const* const Gb = sh.G4[pt][m];
+        double const b0 = Gb[0], b1 = Gb[1], b2 = Gb[2], bN = Gb[3];
         double const g[3] = {w * b0, w * b1, w * b2};
         double tn[Model::ClosedForm::NT];
         C8_UNROLL
@@ -658,11 +668,14 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
         Model::closed_form_flux_column(tn, ek, isp, g, w * bN, db);
         C8_UNROLL
         for (int n = 0; n < E::NN; ++n) {
-          double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
-          r.J[2 * n] += a0 * db[0] + a1 * db[1] + a2 * db[2];
-          r.J[2 * n + 1] += a0 * db[3] + a1 * db[4] + a2 * db[5];
-          r.J1[2 * n] += a0 * db[6] + a1 * db[7] + a2 * db[8];
-          r.J1[2 * n + 1] += a0 * db[10] + a1 * db[11] + a2 * db[12] + aN * db[9];
+          double const* const Ga = sh.G4[pt][n];
+          double const a0 = Ga[0], a1 = Ga[1], a2 = Ga[2], aN = Ga[3];
+          // one fused multiply-add per product, chained through the accumulator (a sum of products added afterwards costs
+          // a multiplication and an addition more per entry: 17 instead of 13 instructions per node)
+          r.J[2 * n] = fma(a2, db[2], fma(a1, db[1], fma(a0, db[0], r.J[2 * n])));
+          r.J[2 * n + 1] = fma(a2, db[5], fma(a1, db[4], fma(a0, db[3], r.J[2 * n + 1])));
+          r.J1[2 * n] = fma(a2, db[8], fma(a1, db[7], fma(a0, db[6], r.J1[2 * n])));
+          r.J1[2 * n + 1] = fma(aN, db[9], fma(a2, db[12], fma(a1, db[11], fma(a0, db[10], r.J1[2 * n + 1]))));
         }
         double const* Fp = sh.F[pt];
         r.R += Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * (isp * bN);
@@ -785,8 +798,15 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
         C8_UNROLL
         for (int n = 0; n < E::NN; ++n) {
           double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
-          r.J[2 * n] += a0 * s0 + a1 * s1 + a2 * s2 + ((ADJOINT && Mechanics::USES_U) ? aN * v0 : 0.);
-          r.J[2 * n + 1] += a0 * u0 + a1 * u1 + a2 * u2 + aN * u3 + ((ADJOINT && Mechanics::USES_U) ? aN * v1 : 0.);
+          // fused multiply-adds chained through the accumulator (see the closed-form phase P)
+          double j0 = fma(a2, s2, fma(a1, s1, fma(a0, s0, r.J[2 * n])));
+          double j1 = fma(aN, u3, fma(a2, u2, fma(a1, u1, fma(a0, u0, r.J[2 * n + 1]))));
+          if constexpr (ADJOINT && Mechanics::USES_U) {
+            j0 = fma(aN, v0, j0);
+            j1 = fma(aN, v1, j1);
+          }
+          r.J[2 * n] = j0;
+          r.J[2 * n + 1] = j1;
         }
         if (!ADJOINT) {  // residual entry b from the flux values (both halves compute it, half 0 stores it)
           double const* Fp = sh.F[pt];

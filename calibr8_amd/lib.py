@@ -115,6 +115,7 @@ SYMBOLS = [
     ("c8_set_scatter_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_get_scatter_mode", C.c_int, [C.c_void_p]),
     ("c8_set_stage_chunk", C.c_int, [C.c_void_p, C.c_int]),
+    ("c8_set_stage_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_shape_cache", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_assign_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("c8_set_gather_early_nodes", C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -150,6 +150,10 @@ int c8_get_scatter_mode(const c8_ctx* ctx);
  * smaller than the element bandwidth of the mesh) through a ring of three chunks.  Default: the whole mesh in one
  * chunk while its stage stays under 12 GB (8.4 KB per hex8, 2.2 KB per tet4 element), else chunks of 262144. */
 int c8_set_stage_chunk(c8_ctx* ctx, int min_chunk);
+/* C8_SCATTER_GATHER in several chunks: on = 1 issues the row sums of chunk k on a stream of the context's own, beside
+ * the assembly of chunk k + 1 on the caller's stream (events order the two both ways; the caller's stream continues
+ * only after the last row sums, so the call keeps its stream semantics).  Same values bit for bit. */
+int c8_set_stage_overlap(c8_ctx* ctx, int on);
 /* C8_SCATTER_GATHER in two parts, for a caller that exchanges ghost rows (LinearAlg::gather_A / gather_b,
  * linear_alg.cpp:53-86): with an early node range set, a Jacobian assembly stages every element and sums the rows of
  * the nodes [node_begin, node_end) only -- the ghost rows, which the caller can then pack and send -- and

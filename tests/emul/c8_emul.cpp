@@ -190,11 +190,13 @@ template <template <class> class ModelT> static void run_wave_adjoint(Call const
 template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
+  // the closed-form kernel has its own shared layout, as on the device (c8_kernels.hip: k_forward_jacobian_wave_closed)
+  auto* shc = new WaveShared<E, ModelT<Dual>::NLOC, false, ModelT<Dual>::FINITE_DEF, true>();
   auto* ex = new CpuExec<WaveLane<ModelT>, 64>();
   auto one = [&](SystemArgs const& sa, int e) {
     if (c.what == K_FORWARD_WAVE) {
       if constexpr (has_closed_form<ModelT<Dual>>::value) {
-        if (c.closed) { forward_jacobian_wave_closed<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e); return; }
+        if (c.closed) { forward_jacobian_wave_closed<E, ModelT>(*ex, *shc, c.mt, c.ms, c.fa, sa, e); return; }
       }
       forward_jacobian_wave<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, sa, e);
     }
@@ -204,6 +206,7 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   else for (int e = 0; e < c.nelems; ++e) one(c.sa, e);
   delete ex;
   delete sh;
+  delete shc;
 }
 
 template <template <class> class ModelT> static void run_residual_wave(Call const& c) {
