@@ -126,8 +126,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    ndev = torch.cuda.device_count()
+    if world > ndev and args.transport == "rccl":
+        # fewer cards than ranks (a rehearsal on a shared card): RCCL admits one rank per card, so the messages go through
+        # the host; same on every rank (one node), and said in config.transport
+        print("rank %d: %d ranks on %d GPU(s): host transport" % (rank, world, ndev), file=sys.stderr)
+        args.transport = "host"
     if args.transport == "host":
-        local_rank = 0
+        local_rank = local_rank % max(ndev, 1) if world > ndev else 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -386,11 +386,12 @@ C8_HD void accumulate_coupled(SH const& sh, int pt, int k, MechFlux<Dual> const&
   C8_UNROLL
   for (int n = 0; n < E::NN; ++n) {
     double const d0 = sh.dN[pt][n][0] * wdv, d1 = sh.dN[pt][n][1] * wdv, d2 = sh.dN[pt][n][2] * wdv;
-    Jcol[D * n + 0] += f.Gu.xx.d * d0 + f.Gu.xy.d * d1 + f.Gu.xz.d * d2;
-    Jcol[D * n + 1] += f.Gu.yx.d * d0 + f.Gu.yy.d * d1 + f.Gu.yz.d * d2;
-    if (D == 3) Jcol[D * n + 2] += f.Gu.zx.d * d0 + f.Gu.zy.d * d1 + f.Gu.zz.d * d2;
+    // fused multiply-adds chained through the accumulator (one instruction per product)
+    Jcol[D * n + 0] = fma(f.Gu.xz.d, d2, fma(f.Gu.xy.d, d1, fma(f.Gu.xx.d, d0, Jcol[D * n + 0])));
+    Jcol[D * n + 1] = fma(f.Gu.yz.d, d2, fma(f.Gu.yy.d, d1, fma(f.Gu.yx.d, d0, Jcol[D * n + 1])));
+    if (D == 3) Jcol[D * n + 2] = fma(f.Gu.zz.d, d2, fma(f.Gu.zy.d, d1, fma(f.Gu.zx.d, d0, Jcol[D * n + 2])));
     if constexpr (E::NRES == 2)
-      Jcol[D * E::NN + n] += f.Vp.d * (sh.N[pt][n] * wdv) + f.Gp[0].d * d0 + f.Gp[1].d * d1 + f.Gp[2].d * d2;
+      Jcol[D * E::NN + n] = fma(f.Gp[2].d, d2, fma(f.Gp[1].d, d1, fma(f.Gp[0].d, d0, fma(f.Vp.d, sh.N[pt][n] * wdv, Jcol[D * E::NN + n]))));
   }
   double const d0 = sh.dN[pt][nk][0] * wdv, d1 = sh.dN[pt][nk][1] * wdv, d2 = sh.dN[pt][nk][2] * wdv;
   double const r0 = f.Gu.xx.v * d0 + f.Gu.xy.v * d1 + f.Gu.xz.v * d2;
