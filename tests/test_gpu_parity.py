@@ -245,6 +245,34 @@ def test_staged_gather_ring_pipeline():
     check_adjoint_chain(orc, gpu, c, "small_J2", 0.004, TOL)
 
 
+def test_staged_gather_row_sums_beside_next_chunk():
+    # c8_set_stage_overlap: the row sums of chunk k on the context's second stream beside the assembly of chunk k + 1
+    # (events both ways, ring slots reused only after their row sums): parity with the oracle, and the same bits as the
+    # one-after-the-other form, over repeated calls into the same system
+    from gpu_backend import GpuBackend
+    c, conn, sets = brick(3, 3, 40, 0.3, 0.3, 4.0)
+    c = jiggle(c, sets, 0.02)
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2)
+    gpu = GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather")
+    gpu.asm.set_stage_chunk(4)
+    gpu.asm.set_stage_overlap(True)
+    check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
+    check_adjoint_chain(orc, gpu, c, "small_J2", 0.004, TOL)
+    u, p = prescribed_fields(c, 0.004, ramp=True)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    out = []
+    for on in (True, False):
+        gpu.asm.set_stage_overlap(on)
+        ls = gpu.new_linsys()
+        for _ in range(3):  # accumulates: three assemblies into the same system
+            assert gpu.forward_jacobian(u, p, z, zp, gpu.new_state(), gpu.new_state(), ls) == 0
+        out.append(ls)
+    for i in range(2):
+        assert np.array_equal(out[0].b[i], out[1].b[i])
+        for j in range(2):
+            assert np.array_equal(out[0].A[i][j], out[1].A[i][j])
+
+
 def test_staged_gather_two_sets_and_reproducible():
     check_two_element_sets(factory("gather", "wave"), "hex8", TOL)
     # two runs are bitwise identical (fixed summation order)
