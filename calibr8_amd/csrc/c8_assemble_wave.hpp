@@ -822,25 +822,19 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     C8_STAMP(5 + 2 * t);
   }
   if constexpr (CLOSED) {
-    // the halves exchange their partial sums: half 0 completes group 0 (J), half 1 completes group 1 (J1) and moves it
-    // into J, which the scatter reads
+    // the halves exchange their partial sums: half 0 completes group 0 (its J and the other half's J), half 1 group 1 (the
+    // other half's J1 and its own), both into J, which the scatter reads.  One lane-pair exchange per accumulator
+    // (EX::pair_sum32: v_permlane32_swap on the device, no LDS traffic and no selects)
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
-      int const hf = lane >> 5;
       C8_UNROLL
-      for (int k = 0; k < 16; ++k) {
-        double const recv = ex.xor32(lane, [&](int l) { auto& rl = ex.lane(l); return (l >> 5) ? rl.J[k] : rl.J1[k]; });
-        if (hf) r.J1[k] += recv; else r.J[k] += recv;
-      }
+      for (int k = 0; k < 16; ++k)
+        r.J[k] = ex.pair_sum32(lane, [&](int l) { return ex.lane(l).J[k]; }, [&](int l) { return ex.lane(l).J1[k]; });
       double const Rr = ex.xor32(lane, [&](int l) { return ex.lane(l).R; });
       r.Rx = Rr;
     });
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
-      if (lane >> 5) {
-        C8_UNROLL
-        for (int k = 0; k < 16; ++k) r.J[k] = r.J1[k];
-      }
       r.R += r.Rx;
     });
   }

@@ -64,6 +64,18 @@ template <class Lane> struct GpuExec {
   }
   // get(l) of lane l ^ 32 (the other half of the wavefront)
   template <class F> __device__ __forceinline__ double xor32(int lane, F get) { return __shfl_xor(get(lane), 32); }
+  // lanes 0..31: getA(lane) + getA(lane + 32); lanes 32..63: getB(lane - 32) + getB(lane).  v_permlane32_swap (gfx950)
+  // exchanges the upper half of one register with the lower half of another: two swaps per double, then one add.
+  template <class FA, class FB> __device__ __forceinline__ double pair_sum32(int lane, FA getA, FB getB) {
+    double const a = getA(lane), b = getB(lane);
+#ifdef C8_TUNE_NO_SWAP32  // tuning build (same results): the exchange through ds_bpermute and selects
+    double const recv = __shfl_xor(lane < 32 ? b : a, 32);
+    return lane < 32 ? a + __shfl_xor(a, 32) + 0. * recv : __shfl_xor(b, 32) + b;
+#endif
+    auto const lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto const hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
 #ifdef C8_STAMPS
   // element e is sampled when e % 244 == 0 (4096 samples over a 1M-element mesh)
   __device__ __forceinline__ void stamp(SystemArgs const& sa, int e, int i) {

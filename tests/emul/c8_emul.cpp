@@ -47,6 +47,25 @@ template <class Lane, int NDOF> struct CpuExec {
     return v;
   }
   // get() of lane ^ 32 (GpuExec: a shuffle).  Sound here where no lane changes during an each() what its partner reads.
+  // lanes 0..31: getA(lane) + getA(lane + 32); lanes 32..63: getB(lane - 32) + getB(lane) (GpuExec: v_permlane32_swap).
+  // Sound where no lane overwrites during the each() what a LATER lane reads: the caller stores the result in the A
+  // register, which only lanes below 32 read from their partners, and those have run by then.
+  template <class FA, class FB> double pair_sum32(int lane, FA getA, FB getB) {
+    int const saved = cur, other = lane ^ 32;
+    double r;
+    if (lane < 32) {
+      double const own = getA(lane);
+      cur = other;
+      r = own + getA(other);
+    } else {
+      cur = other;
+      double const o = getB(other);
+      cur = saved;
+      r = o + getB(lane);
+    }
+    cur = saved;
+    return r;
+  }
   template <class F> double xor32(int lane, F get) {
     int const saved = cur;
     cur = lane ^ 32;
