@@ -10,6 +10,11 @@
 
 namespace c8 {
 
+#ifdef C8_TUNE_VECTOR_WIB  // tuning build (same results): the wave's index in its block as a vector value
+#define C8_WAVE_IN_BLOCK(WPB) (threadIdx.x >> 6)
+#else
+#define C8_WAVE_IN_BLOCK(WPB) ((WPB) == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6))
+#endif
 #ifndef C8_BLOCK
 #define C8_BLOCK 64
 #endif
@@ -165,7 +170,9 @@ k_forward_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArg
   __shared__ WaveShared<E, ModelT<Dual>::NLOC, false, ModelT<Dual>::FINITE_DEF> shs[WPB];
   int const lb = (sa.stage && STAGE_STRIPE) ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
   if (gi >= count) return;
   int const e = mt.order ? mt.order[first + gi] : first + gi;
@@ -187,7 +194,9 @@ k_forward_jacobian_wave_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, Sy
   __shared__ WaveShared<E, ModelT<Dual>::NLOC, false, ModelT<Dual>::FINITE_DEF, true> shs[WPB];
   int const lb = (sa.stage && STAGE_STRIPE) ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
   if (gi >= count) return;
   int const e = mt.order ? mt.order[first + gi] : first + gi;
@@ -223,7 +232,9 @@ k_adjoint_jacobian_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointAr
   __shared__ WaveShared<E, ModelT<Dual>::NLOC, true, ModelT<Dual>::FINITE_DEF> shs[WPB];
   int const lb = (sa.stage && STAGE_STRIPE) ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
   if (gi >= count) return;
   int const e = mt.order ? mt.order[first + gi] : first + gi;
@@ -257,7 +268,9 @@ k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs 
   __shared__ WaveSharedA<E, ModelT<Dual>::NLOC> shs[WPB];
   int const lb = STAGE_STRIPE ? xcd_stripe(blockIdx.x, STAGE_STRIPE) : xcd_block(blockIdx.x, nblocks);  // per-element outputs only: stripes
   if (lb >= nblocks) return;
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
   if (gi >= count) return;
   Lane L;
@@ -270,7 +283,9 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k
   constexpr int WPB = BLOCK / 64;
   using Lane = GradWaveLane<ModelT>;
   __shared__ GradWaveShared<E> shs[WPB];
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   Lane L;
   L.slot0 = -1;
   C8_UNROLL
@@ -325,7 +340,9 @@ __global__ void __launch_bounds__(BLOCK, 2) k_residual_wave(MeshTables mt, Model
   __shared__ ResidualWaveShared<E> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   int const e0 = (lb * WPB + wib) * 8;
   if (e0 >= count) return;
   Lane L;
@@ -348,7 +365,9 @@ __global__ void __launch_bounds__(BLOCK) k_gather_rows(GatherArgs ga, int first,
   __shared__ GatherShared<E, MAXDEG> shs[WPB];
   int const lb = xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks) return;
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   int const gi = lb * WPB + wib;
   if (gi >= count) return;
   GatherLane<E, MAXDEG> L;
@@ -451,7 +470,9 @@ __global__ void __launch_bounds__(BLOCK, 2) k_qoi_wave(MeshTables mt, FieldArgs 
   constexpr int WPB = BLOCK / 64;
   using Lane = QoiWaveLane<ModelT>;
   __shared__ GradWaveShared<E> shs[WPB];
-  int const wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave's index in the block is wave-uniform: as a scalar it keeps the element / node number and every address
+  // derived from it in SGPRs (one wave per block: zero)
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
   Lane L;
   L.acc = 0.;
   GpuExec<Lane> ex(lane, L);
