@@ -52,7 +52,13 @@ __global__ void k_traction(int n, int npf, int32_t const* faces, double const* t
   double X[4][3];
   for (int a = 0; a < npf; ++a)
     for (int d = 0; d < 3; ++d) X[a][d] = coords[(size_t)fn[a] * 3 + d];
-  if (npf == 3) {  // order-1 rule: centroid, w = 1/2, dv = 2 * area, N = 1/3
+  if (npf == 2) {  // sides of a 2-D mesh: edges, order-1 rule: midpoint, w = 2, dv = length / 2, N = 1/2; two equations per node
+    double const ex = X[1][0] - X[0][0], ey = X[1][1] - X[0][1];
+    double const len = sqrt(ex * ex + ey * ey);
+    double const* T = traction + (size_t)f * 3;
+    for (int a = 0; a < 2; ++a)
+      for (int d = 0; d < 2; ++d) unsafeAtomicAdd(&b[(size_t)fn[a] * 2 + d], -(T[d] * 0.5 * len));
+  } else if (npf == 3) {  // order-1 rule: centroid, w = 1/2, dv = 2 * area, N = 1/3
     double const e1[3] = {X[1][0] - X[0][0], X[1][1] - X[0][1], X[1][2] - X[0][2]};
     double const e2[3] = {X[2][0] - X[0][0], X[2][1] - X[0][1], X[2][2] - X[0][2]};
     double const cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
@@ -156,10 +162,11 @@ int c8_apply_dirichlet(c8_ctx* c, int n, const c8_dbc* dbcs, const double* const
 
 int c8_apply_traction(c8_ctx* c, int n, const c8_tbc* tbcs, const c8_system* sys) {
   if (!c || n < 0 || (n > 0 && !tbcs) || !sys) return c8_fail(C8_ERR_ARG, "c8_apply_traction: null argument");
-  if (n > 0 && c->ndims != 3) return c8_fail(C8_ERR_UNSUPPORTED, "c8_apply_traction: tractions are built for the faces of 3-D elements");
+
   for (int q = 0; q < n; ++q) {
     c8_tbc const& t = tbcs[q];
-    if (t.resid != 0 || (t.nodes_per_face != 3 && t.nodes_per_face != 4)) return c8_fail(C8_ERR_ARG, "c8_apply_traction: tractions act on residual 0 over tri3/quad4 faces");
+    bool const side_ok = c->ndims == 2 ? t.nodes_per_face == 2 : (t.nodes_per_face == 3 || t.nodes_per_face == 4);
+    if (t.resid != 0 || !side_ok) return c8_fail(C8_ERR_ARG, "c8_apply_traction: tractions act on residual 0 over the sides of the mesh (edges of a 2-D mesh, tri3 / quad4 faces of a 3-D mesh)");
     if (t.n <= 0) continue;
     hipLaunchKernelGGL(k_traction, dim3(grid_of(t.n)), dim3(TPB), 0, c->stream, t.n, t.nodes_per_face, t.faces, t.traction,
                        c->d_coords, sys->b[0]);
@@ -169,11 +176,13 @@ int c8_apply_traction(c8_ctx* c, int n, const c8_tbc* tbcs, const c8_system* sys
 }
 
 int c8_face_points(int npf, int n, const double* coords, const int32_t* faces, double* xyz) {
-  if ((npf != 3 && npf != 4) || n < 0 || !coords || !faces || !xyz) return c8_fail(C8_ERR_ARG, "c8_face_points: bad argument");
+  if ((npf < 2 || npf > 4) || n < 0 || !coords || !faces || !xyz) return c8_fail(C8_ERR_ARG, "c8_face_points: bad argument");
   double const g = 0.5773502691896257645;
   for (int f = 0; f < n; ++f) {
     int32_t const* fn = faces + (size_t)f * npf;
-    if (npf == 3) {
+    if (npf == 2) {
+      for (int d = 0; d < 3; ++d) xyz[(size_t)f * 3 + d] = 0.5 * (coords[(size_t)fn[0] * 3 + d] + coords[(size_t)fn[1] * 3 + d]);
+    } else if (npf == 3) {
       for (int d = 0; d < 3; ++d)
         xyz[(size_t)f * 3 + d] = (coords[(size_t)fn[0] * 3 + d] + coords[(size_t)fn[1] * 3 + d] + coords[(size_t)fn[2] * 3 + d]) / 3.;
     } else {

@@ -150,7 +150,7 @@ class PrimalDriver:
         for _, faces, _ in self.tbcs:
             f = np.ascontiguousarray(faces, dtype=np.int32)
             npf = f.shape[1]
-            pts = np.zeros((len(f), 1 if npf == 3 else 4, 3))
+            pts = np.zeros((len(f), 4 if npf == 4 else 1, 3))
             _l.check(L.c8_face_points(npf, len(f), asm.coords.ctypes.data_as(_l.dp), f.ctypes.data_as(_l.i32p),
                                       pts.ctypes.data_as(_l.dp)))
             self._tbc_faces.append(torch.as_tensor(f, device=dev))

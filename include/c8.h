@@ -253,19 +253,19 @@ typedef struct {
   const int32_t* nodes;   /* [n] local node ids */
   const double* values;   /* [n] */
 } c8_dbc;
-/* One traction condition (tbcs.cpp:17-86) on boundary faces: tri3 faces of tet4 meshes with the
- * reference's 1-point rule, quad4 faces of hex8 meshes with the 2x2 rule.  DEVICE pointers. */
+/* One traction condition (tbcs.cpp:17-86) on the sides of the mesh: tri3 faces of tet4 meshes and the edges of tri3
+ * meshes with the reference's 1-point rule, quad4 faces of hex8 meshes with the 2x2 rule.  DEVICE pointers. */
 typedef struct {
-  int32_t resid, n, nodes_per_face;  /* 3 or 4 */
+  int32_t resid, n, nodes_per_face;  /* 2 (edges of a 2-D mesh), 3 or 4 */
   const int32_t* faces;    /* [n][nodes_per_face] local node ids */
-  const double* traction;  /* [n][points][3], points = 1 (tri3) or 4 (quad4) */
+  const double* traction;  /* [n][points][3], points = 1 (edge, tri3) or 4 (quad4); on a 2-D mesh the third entry is ignored */
 } c8_tbc;
 /* apply_primal_dbcs (dbcs.cpp:28-121): for every constrained row keep the diagonal entry, zero the rest
  * of the row in every block, b[row] = diag * (x[row] - value), or 0 when is_adjoint. */
 int c8_apply_dirichlet(c8_ctx* ctx, int n, const c8_dbc* dbcs, const double* const x[2], const c8_system* sys, int is_adjoint);
 /* apply_primal_tbcs (tbcs.cpp:88-98): b[row(node, d)] -= T_d N_node w dv over the faces. */
 int c8_apply_traction(c8_ctx* ctx, int n, const c8_tbc* tbcs, const c8_system* sys);
-/* Integration points of boundary faces (HOST arrays): xyz [n][points][3], for evaluating traction expressions. */
+/* Integration points of boundary sides (HOST arrays; coords [.][3]): xyz [n][points][3], for evaluating traction expressions. */
 int c8_face_points(int nodes_per_face, int n, const double* coords, const int32_t* faces, double* xyz);
 /* LinearAlg::apply_A (linear_alg.cpp:158-175): y = A x over the four blocks (DEVICE pointers). */
 int c8_apply_A(c8_ctx* ctx, const c8_system* sys, const double* const x[2], double* const y[2]);

@@ -88,9 +88,19 @@ def apply_dbcs(be, ls, dbcs, x, coords, t, is_adjoint=False):
 
 
 def apply_tbcs(ls, tbcs, coords, t):
-    """tbcs.cpp:17-86 on tri3 boundary faces with the order-1 rule (centroid, N = 1/3)."""
+    """tbcs.cpp:17-86 on tri3 boundary faces with the order-1 rule (centroid, N = 1/3); on a 2-D mesh the sides are
+    edges (midpoint, N = 1/2, w dv = length) and a node has two equations."""
     for bc in tbcs:
         for tri in bc.sides:
+            if len(tri) == 2:
+                X = coords[list(tri)]
+                length = np.linalg.norm(X[1] - X[0])
+                xc = X.mean(axis=0)
+                T = bc.fn(xc[0], xc[1], xc[2], t)
+                for n in tri:
+                    for d in range(2):
+                        ls.b[bc.resid][n * 2 + d] -= T[d] * 0.5 * length
+                continue
             X = coords[list(tri)]
             area = 0.5 * np.linalg.norm(np.cross(X[1] - X[0], X[2] - X[0]))
             xc = X.mean(axis=0)

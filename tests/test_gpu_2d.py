@@ -310,3 +310,64 @@ def test_synthetic_calibration_2d_objective_and_gradient_on_device():
         pm[act] -= h * direction
         errs.append(abs((solve(pp, measured).qoi() - solve(pm, measured).qoi()) / (2 * h) - gd))
     assert min(errs) < 1e-6 * abs(gd), (errs, gd)
+
+
+def boundary_edges_on(conn, nodes):
+    """edges of a tri3 mesh that belong to one triangle only and whose two nodes lie in `nodes` (a side set of a 2-D mesh)"""
+    count = {}
+    for tri in conn:
+        for a, b in ((tri[0], tri[1]), (tri[1], tri[2]), (tri[2], tri[0])):
+            key = (min(int(a), int(b)), max(int(a), int(b)))
+            count[key] = count.get(key, 0) + 1
+    inside = set(int(n) for n in nodes)
+    return np.array([k for k, v in count.items() if v == 1 and k[0] in inside and k[1] in inside], dtype=np.int32)
+
+
+@pytest.mark.parametrize("global_type,model,params", [
+    ("mechanics", "small_J2", [1000.0, 0.25, 100.0, 10.0, 0.0, 0.0]),
+    ("mechanics_plane_stress", "small_hill_plane_stress", [1000.0, 0.25, 2.0, 10.0, 2.0, 1.0, 1.0, 1.0, 1.0])])
+def test_2d_tractions_on_device(global_type, model, params):
+    # tbcs.cpp:17-86 on a 2-D mesh: the sides are edges (order-1 rule: midpoint, N = 1/2, w dv = length), two equations per
+    # node.  (1) the device kernel equals the host restatement, a constant traction integrates to T * length of the side
+    # set; (2) a traction-driven load history through c8_primal_solve_step takes the Newton iterations of the
+    # oracle-driven host driver and lands on the same objective.
+    import torch
+    from calibr8_amd import Assembler
+    from calibr8_amd import lib as L
+    from calibr8_amd.primal import PrimalDriver
+    from fe_driver import Dbc, Primal, Tbc, apply_tbcs
+    c, conn, ns = notch2d()
+    edges = boundary_edges_on(conn, ns["ymax"])
+    assert len(edges) == len(ns["ymax"]) - 1
+    asm = Assembler(3, c, conn, model, params)  # the global residual follows the model's name, as in the reference's decks
+    orc = ol.Oracle(ol.TRI3, c, conn, model, params)
+    assert asm.nres == (1 if global_type == "mechanics_plane_stress" else 2)
+    # (1) kernel against the host restatement
+    fn = lambda x, y, z, t: (0.3 * x + 0.1, 2.0 - 0.5 * x * x, 0.0)
+    pts = np.zeros((len(edges), 1, 3))
+    L.check(asm.L.c8_face_points(2, len(edges), asm.coords.ctypes.data_as(L.dp), edges.ctypes.data_as(L.i32p), pts.ctypes.data_as(L.dp)))
+    assert np.allclose(pts[:, 0, :], 0.5 * (c[edges[:, 0]] + c[edges[:, 1]]), atol=1e-15)
+    tr = np.array([[fn(*p, 0.0) for p in fp] for fp in pts])
+    ls = asm.new_linsys()
+    asm.apply_traction([(0, torch.as_tensor(edges, device=asm.device), asm.dev(tr.ravel()))], ls)
+    ref = orc.new_linsys()
+    apply_tbcs(ref, [Tbc(0, [tuple(e) for e in edges], fn)], c, 0.0)
+    b = ls.b[0].cpu().numpy()
+    assert np.abs(b - ref.b[0]).max() < 1e-14 * np.abs(ref.b[0]).max()
+    ls.zero()
+    asm.apply_traction([(0, torch.as_tensor(edges, device=asm.device), asm.dev(np.tile([0.0, 2.0, 0.0], len(edges))))], ls)
+    length = np.linalg.norm(c[edges[:, 1]] - c[edges[:, 0]], axis=1).sum()
+    b = ls.b[0].cpu().numpy().reshape(-1, 2)
+    assert abs(b[:, 1].sum() + 2.0 * length) < 1e-12 and abs(b[:, 0].sum()) < 1e-14
+    # a 3-D side on a 2-D mesh is refused
+    with pytest.raises(L.C8Error):
+        asm.apply_traction([(0, torch.zeros((1, 3), dtype=torch.int32, device=asm.device), asm.dev(np.zeros(3)))], ls)
+    # (2) traction-driven steps into the plastic range
+    zero = lambda x, y, z, t: 0.0
+    dbcs = [(0, 0, ns["xmin"], zero), (0, 1, ns["ymin"], zero)]
+    pull = lambda x, y, z, t: (0.0, 3.0 * t, 0.0)
+    drv = PrimalDriver(asm, dbcs, [(0, edges, pull)], max_iters=20).solve(3)
+    pr = Primal(orc, c, [Dbc(r, e, n, f) for r, e, n, f in dbcs], [Tbc(0, [tuple(e) for e in edges], pull)], max_iters=20).solve(3)
+    assert drv.newton_iters == pr.newton_iters, (drv.newton_iters, pr.newton_iters)
+    assert abs(drv.qoi() - pr.qoi()) < 1e-9 * abs(pr.qoi())
+    assert float(drv.xi[-1][:, :, -1].max()) > 1e-4  # plastic
