@@ -409,8 +409,10 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     auto& r = ex.lane(lane);
     r.failed = false;
     r.R = 0.;
-    C8_UNROLL
-    for (int a = 0; a < 16; ++a) r.J[a] = r.J1[a] = 0.;
+    if constexpr (!CLOSED) {  // (the closed-form phase P assigns its accumulators at its first point)
+      C8_UNROLL
+      for (int a = 0; a < 16; ++a) r.J[a] = r.J1[a] = 0.;
+    }
     if (lane == 0) sh.failed = 0;
     {
       int const pt = lane >> 3, d = lane & 7;
@@ -654,8 +656,10 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       double const ek[3] = {k == 0 ? 1. : 0., k == 1 ? 1. : 0., k == 2 ? 1. : 0.};
       double const isp = bu ? 0. : 1.;
       int const cg = bu ? 3 * k : 10;
-      C8_NOUNROLL
-      for (int q4 = 0; q4 < 4; ++q4) {
+      // the first point of a half assigns the accumulators (a product instead of the first fused multiply-add: no pass that
+      // zeroes 32 accumulators), the other three add to them
+      auto point = [&](int q4, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         int const pt = 4 * hf + q4;
         double const w = sh.wdv[pt];
         double const* const Gb = sh.G4[pt][m];
@@ -672,14 +676,17 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
           double const a0 = Ga[0], a1 = Ga[1], a2 = Ga[2], aN = Ga[3];
           // one fused multiply-add per product, chained through the accumulator (a sum of products added afterwards costs
           // a multiplication and an addition more per entry: 17 instead of 13 instructions per node)
-          r.J[2 * n] = fma(a2, db[2], fma(a1, db[1], fma(a0, db[0], r.J[2 * n])));
-          r.J[2 * n + 1] = fma(a2, db[5], fma(a1, db[4], fma(a0, db[3], r.J[2 * n + 1])));
-          r.J1[2 * n] = fma(a2, db[8], fma(a1, db[7], fma(a0, db[6], r.J1[2 * n])));
-          r.J1[2 * n + 1] = fma(aN, db[9], fma(a2, db[12], fma(a1, db[11], fma(a0, db[10], r.J1[2 * n + 1]))));
+          r.J[2 * n] = fma(a2, db[2], fma(a1, db[1], FIRST ? a0 * db[0] : fma(a0, db[0], r.J[2 * n])));
+          r.J[2 * n + 1] = fma(a2, db[5], fma(a1, db[4], FIRST ? a0 * db[3] : fma(a0, db[3], r.J[2 * n + 1])));
+          r.J1[2 * n] = fma(a2, db[8], fma(a1, db[7], FIRST ? a0 * db[6] : fma(a0, db[6], r.J1[2 * n])));
+          r.J1[2 * n + 1] = fma(aN, db[9], fma(a2, db[12], fma(a1, db[11], FIRST ? a0 * db[10] : fma(a0, db[10], r.J1[2 * n + 1]))));
         }
         double const* Fp = sh.F[pt];
         r.R += Fp[cg] * b0 + Fp[cg + 1] * b1 + Fp[cg + 2] * b2 + Fp[9] * (isp * bN);
-      }
+      };
+      point(0, std::true_type{});
+      C8_NOUNROLL
+      for (int q4 = 1; q4 < 4; ++q4) point(q4, std::false_type{});
     });
   } else
   // ---- phases D and P, 4 points per pass -------------------------------------------------------------
