@@ -65,7 +65,8 @@ def main():
         return a.elapsed_time(b) / args.reps
 
     res = {}
-    variants = ("slot",) if args.tet else ("wave", "slot")
+    # staged (gather) mode: the hex8 lane-group adjoint kernel cannot stage, time the wave-per-element kernels only
+    variants = ("slot",) if args.tet else (("wave",) if args.scatter == "gather" else ("wave", "slot"))
     for k in variants:
         asm.set_kernel(k)
         res["forward_jacobian_" + k] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))

@@ -24,6 +24,10 @@ timeout -k 10 300 python3 tools/bench_kernels.py --model hyper_J2 > $O/kernels_h
 timeout -k 10 300 python3 tools/bench_kernels.py --model small_hill > $O/kernels_small_hill.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model hypo_hill > $O/kernels_hypo_hill.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --tet --edge 56 --scatter gather > $O/kernels_tet4_gather.json 2>/dev/null || exit 1
+# the same in the library's default mode (staged assembly + row sums) for the four hex8 models
+for m in small_J2 hyper_J2 small_hill hypo_hill; do
+  timeout -k 10 300 python3 tools/bench_kernels.py --model $m --scatter gather > $O/kernels_${m}_gather.json 2>/dev/null || exit 1
+done
 echo kernels done
 timeout -k 10 400 python3 tools/bench_fractions.py > $O/fractions.json 2>/dev/null || exit 1
 echo all done

@@ -32,4 +32,5 @@ put("bench_colored.json", "bench_wave_colored_100cube.json")
 put("fractions.json", "plastic_fractions_100cube.json")
 for m in ("small_J2", "hyper_J2", "small_hill", "hypo_hill"):
     put("kernels_%s.json" % m, "all_kernels_%s_100cube.json" % m)
+    put("kernels_%s_gather.json" % m, "all_kernels_%s_100cube_gather.json" % m)
 put("kernels_tet4_gather.json", "all_kernels_tet4_1M_gather.json")
