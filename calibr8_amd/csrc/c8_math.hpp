@@ -187,17 +187,26 @@ template <class S, class T> C8_HD Tens3<T> scale(S const& s, Tens3<T> const& A) 
   r.zx = s * A.zx; r.zy = s * A.zy; r.zz = s * A.zz;
   return r;
 }
+// a1 b1 + a2 b2 + a3 b3 as one chain of fused multiply-adds: 3 instructions for doubles, 3 + 6 for dual numbers (the
+// operator form adds three separately rounded products: 3 + 8)
+C8_HD double dot3(double a1, double b1, double a2, double b2, double a3, double b3) {
+  return fma(a3, b3, fma(a2, b2, a1 * b1));
+}
+C8_HD Dual dot3(Dual const& a1, Dual const& b1, Dual const& a2, Dual const& b2, Dual const& a3, Dual const& b3) {
+  return Dual(fma(a3.v, b3.v, fma(a2.v, b2.v, a1.v * b1.v)),
+              fma(a3.d, b3.v, fma(a3.v, b3.d, fma(a2.d, b2.v, fma(a2.v, b2.d, fma(a1.d, b1.v, a1.v * b1.d))))));
+}
 template <class T> C8_HD Tens3<T> matmul(Tens3<T> const& A, Tens3<T> const& B) {
   Tens3<T> r;
-  r.xx = A.xx * B.xx + A.xy * B.yx + A.xz * B.zx;
-  r.xy = A.xx * B.xy + A.xy * B.yy + A.xz * B.zy;
-  r.xz = A.xx * B.xz + A.xy * B.yz + A.xz * B.zz;
-  r.yx = A.yx * B.xx + A.yy * B.yx + A.yz * B.zx;
-  r.yy = A.yx * B.xy + A.yy * B.yy + A.yz * B.zy;
-  r.yz = A.yx * B.xz + A.yy * B.yz + A.yz * B.zz;
-  r.zx = A.zx * B.xx + A.zy * B.yx + A.zz * B.zx;
-  r.zy = A.zx * B.xy + A.zy * B.yy + A.zz * B.zy;
-  r.zz = A.zx * B.xz + A.zy * B.yz + A.zz * B.zz;
+  r.xx = dot3(A.xx, B.xx, A.xy, B.yx, A.xz, B.zx);
+  r.xy = dot3(A.xx, B.xy, A.xy, B.yy, A.xz, B.zy);
+  r.xz = dot3(A.xx, B.xz, A.xy, B.yz, A.xz, B.zz);
+  r.yx = dot3(A.yx, B.xx, A.yy, B.yx, A.yz, B.zx);
+  r.yy = dot3(A.yx, B.xy, A.yy, B.yy, A.yz, B.zy);
+  r.yz = dot3(A.yx, B.xz, A.yy, B.yz, A.yz, B.zz);
+  r.zx = dot3(A.zx, B.xx, A.zy, B.yx, A.zz, B.zx);
+  r.zy = dot3(A.zx, B.xy, A.zy, B.yy, A.zz, B.zy);
+  r.zz = dot3(A.zx, B.xz, A.zy, B.yz, A.zz, B.zz);
   return r;
 }
 template <class T> C8_HD Tens3<T> transpose(Tens3<T> const& A) {
@@ -228,7 +237,7 @@ template <class T> C8_HD Tens3<T> cofactor(Tens3<T> const& F) {
 }
 template <class T> C8_HD Tens3<T> inverse(Tens3<T> const& A) {
   Tens3<T> const C = cofactor(A);
-  T const dt = A.xx * C.xx + A.xy * C.xy + A.xz * C.xz;
+  T const dt = dot3(A.xx, C.xx, A.xy, C.xy, A.xz, C.xz);
   T const r = 1. / dt;
   return scale(r, transpose(C));
 }
