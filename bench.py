@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--stage-chunk", type=int, default=0, help="scatter=gather: minimum elements per staged chunk")
     ap.add_argument("--assign", action="store_true", help="scatter=gather: c8_set_assign_mode (zero_all + assembly in one call); "
                     "NOT the default: the contract metric is the accumulate-into assembly")
+    ap.add_argument("--workload", default="brick", choices=["brick", "notch"],
+                    help="brick (default: the contract workload); notch = BASELINE config 3's geometry, a double-edge-notched "
+                         "hex8 bar of about edge^3 elements per GPU (tests/meshes.py notched_bar), cut into slabs along the bar for N > 1")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the ghost rows after the whole assembly")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -153,7 +156,21 @@ def main():
         block = tuple(n // q for q in pdims)
     else:
         block = (n, n, n)
-    part = D.brick_part(rank, pdims, block, edge=block[0] / n)
+    if args.workload == "notch":
+        # about n^3 elements per GPU: a (4 : 1 : 1) bar, 15 % of whose elements the two notches remove; slabs along the bar
+        from meshes import notched_bar
+        assert args.scaling == "weak", "--workload notch is weak-scaled"
+        ny = max(4, int(round(0.64 * n)))
+        nx = max(8, int(round(world * n ** 3 / (0.85 * ny * ny))))
+        gc, gconn, _ = notched_bar(nx, ny, ny)
+        order = np.argsort(gc[gconn].mean(axis=1)[:, 0], kind="stable")
+        elem_part = np.empty(len(gconn), dtype=np.int32)
+        elem_part[order] = (np.arange(len(gconn)) * world) // len(gconn)
+        part = D.part_from_global(gc, gconn, elem_part, rank, world)
+        block, pdims = (nx, ny, ny), (world, 1, 1)
+        del gc, gconn, order, elem_part
+    else:
+        part = D.brick_part(rank, pdims, block, edge=block[0] / n)
     plan = D.HaloPlan(part, dist if world > 1 else None)
     coords = plan.coords
     asm = Assembler(8, coords, part.conn, "small_J2", J2, device=str(dev), scatter=args.scatter,
@@ -338,9 +355,14 @@ def main():
         "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%dx%dx%d hex8 brick per GPU (%d elements, %d nodes)%s, small_J2 E1000 nu0.25 K100 Y2, "
+        "config": {"workload": ("double-edge-notched hex8 bar (BASELINE config 3's geometry: the %dx%dx%d brick minus two V-notches; "
+                                "%d elements, %d nodes on this GPU%s), small_J2 E1000 nu0.25 K100 Y2, prescribed ramped uniaxial state "
+                                "eps=0.004 seed 1234, residual+Jacobian assembly"
+                                % (block[0], block[1], block[2], asm.nelems, asm.nnodes, ", slabs along the bar" if world > 1 else ""))
+                               if args.workload == "notch" else
+                               "%dx%dx%d hex8 brick per GPU (%d elements, %d nodes)%s, small_J2 E1000 nu0.25 K100 Y2, "
                                "prescribed ramped uniaxial state eps=0.004 seed 1234, residual+Jacobian assembly; a "
-                               "structured brick stands in for the notched specimen (SURVEY.md 8d)"
+                               "structured brick stands in for the notched specimen (SURVEY.md 8d; --workload notch times that one)"
                                % (block[0], block[1], block[2], asm.nelems, asm.nnodes,
                                   " = the %d^3 brick (BASELINE config 4) split %dx%dx%d" % ((n,) + tuple(pdims)) if args.scaling == "strong" and world > 1 else ""),
                    "elements_per_gpu": asm.nelems, "elements_total": nelems_total, "plastic_fraction": plastic_frac,
@@ -364,7 +386,7 @@ def main():
         nnz_total = sum(asm.nnz[i][j] for i in range(2) for j in range(2))
         balg = algorithmic_bytes(asm.nelems, asm.nnodes, nnz_total)
         achieved = balg / (kernel_ms * 1e-3) / 1e9
-        prof, prof_other = pmc_profile(block[0] if block[0] == block[1] == block[2] else -1, args.scatter,
+        prof, prof_other = pmc_profile(block[0] if block[0] == block[1] == block[2] and args.workload == "brick" else -1, args.scatter,
                                        args.kernel if args.kernel in ("slot", "wave_ad") else "wave", build_id)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,

@@ -22,6 +22,26 @@ def brick(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
     return coords, conn, sets
 
 
+def notched_bar(nx, ny, nz, lx=4.0, ly=1.0, lz=1.0, depth=0.3, halfwidth=0.25):
+    """Double-edge-notched tensile specimen in hex8 (BASELINE config 3): the brick of `brick` with two V-notches cut at
+    mid-length from the faces y = 0 and y = ly (elements whose centre lies inside a notch are removed, the nodes they
+    leave unused are dropped and the rest renumbered in the old order).  Node degrees then vary along the notch flanks:
+    this is the unstructured case of the staged assembly and of the node graphs.  Returns coords, conn, node sets."""
+    coords, conn, _ = brick(nx, ny, nz, lx, ly, lz)
+    ctr = coords[conn].mean(axis=1)
+    reach = depth * ly * np.clip(1.0 - np.abs(ctr[:, 0] - 0.5 * lx) / (halfwidth * lx), 0.0, None)  # notch depth at x
+    keep = (ctr[:, 1] >= reach) & (ctr[:, 1] <= ly - reach)
+    conn = conn[keep]
+    used = np.zeros(len(coords), dtype=bool)
+    used[conn.ravel()] = True
+    new_id = np.cumsum(used) - 1
+    coords, conn = coords[used], new_id[conn].astype(np.int32)
+    tol = 1e-12
+    sets = {"xmin": np.where(coords[:, 0] < tol)[0], "xmax": np.where(coords[:, 0] > lx - tol)[0],
+            "zmin": np.where(coords[:, 2] < tol)[0], "zmax": np.where(coords[:, 2] > lz - tol)[0]}
+    return np.ascontiguousarray(coords), np.ascontiguousarray(conn), sets
+
+
 def tri_mesh(nx, ny, lx=1.0, ly=1.0):
     """Structured tri3 mesh of a rectangle (each cell split along alternating diagonals), counter-clockwise triangles;
     coords [n][3] with z = 0 (the layout the 2-D path takes)."""

@@ -702,3 +702,102 @@ def test_baseline_config2_bar_100k_matches_oracle():
     errs["xi"] = rel_vec(xg, xo)
     assert max(errs.values()) < TOL, errs
     assert 0.2 < (xo[:, :, 6] > 0).mean() < 0.99  # elastic and plastic points both present
+
+
+@pytest.mark.parametrize("model,params,eps", [("small_J2", J2, 0.004), ("hyper_J2", HJ2, 0.004)])
+@pytest.mark.parametrize("scatter", ["gather", "atomic", "colored"])
+def test_notched_specimen_matches_oracle(model, params, eps, scatter):
+    # BASELINE config 3's geometry in small: a double-edge-notched hex8 bar (elements removed from a brick, node degrees
+    # varying along the notch flanks -- the unstructured case of the graphs, the colouring and the staged assembly),
+    # every entry point against the oracle at 1e-12
+    from gpu_backend import GpuBackend
+    from meshes import notched_bar
+    c, conn, sets = notched_bar(24, 12, 6)
+    c = jiggle(c, sets, 0.01)
+    orc = ol.Oracle(ol.HEX8, c, conn, model, params)
+    gpu = GpuBackend(ol.HEX8, c, conn, model, params, scatter=scatter)
+    for i in range(2):
+        for j in range(2):
+            assert np.array_equal(gpu.rowptr[i][j], orc.rowptr[i][j]) and np.array_equal(gpu.colidx[i][j], orc.colidx[i][j])
+    deg = np.diff(orc.rowptr[1][1])
+    assert deg.min() < 27 and len(np.unique(deg)) > 4   # not a brick
+    check_forward(orc, gpu, c, model, eps, TOL)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+
+
+def test_full_size_notched_specimen_properties():
+    # BASELINE config 3 at its size: 1.0 M hex8 elements of a double-edge-notched bar (290 x 64 x 64 brick minus the
+    # notches), small_J2, primal and adjoint assembly, through size-independent properties on the device:
+    #  (1) staged assembly bitwise reproducible and equal to the atomic one to rounding, states equal;
+    #  (2) global equilibrium of the internal forces; J t = 0 for rigid translations;
+    #  (3) K3 with zero histories is K1's transpose: y . (A_K3 x) = x . (A_K1 y);
+    #  (4) K1 at 200 sampled elements (as stand-alone meshes) equals the ORACLE's element matrices at 1e-12.
+    import torch
+    from calibr8_amd import Assembler
+    from meshes import notched_bar
+    coords, conn, _ = notched_bar(290, 64, 64)
+    assert 0.95e6 < len(conn) < 1.06e6
+    asm = Assembler(8, coords, conn, "small_J2", J2)
+    assert asm.scatter == "gather"
+    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    xi0, xi = asm.new_state(), asm.new_state()
+    l1 = asm.new_linsys()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, xi, l1) == 0
+    frac = float((xi[:, :, 6] > 0).double().mean())
+    assert 0.2 < frac < 0.8
+    l1b, xib = asm.new_linsys(), asm.new_state()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, xib, l1b) == 0
+    assert torch.equal(l1.flat, l1b.flat) and torch.equal(xi, xib)
+    asm.set_scatter("atomic")
+    l1b.zero()
+    assert asm.forward_jacobian(u, p, z, zp, xi0, xib, l1b) == 0
+    assert float((l1b.flat - l1.flat).abs().max() / l1.flat.abs().max()) < 1e-13 and torch.equal(xi, xib)
+    del l1b, xib
+    asm.set_scatter("gather")
+    # (2)
+    Ru = l1.b[0].view(-1, 3)
+    assert float(Ru.sum(0).abs().max()) < 1e-9 * float(Ru.abs().sum())
+    for k in range(3):
+        t = torch.zeros_like(u).view(-1, 3)
+        t[:, k] = 1.0
+        yu, yp = torch.zeros_like(u), torch.zeros_like(p)
+        asm.apply_A(l1, t.view(-1).contiguous(), zp, yu, yp)
+        scale = float(l1.A[0][0].abs().max())
+        assert float(yu.abs().max()) < 1e-10 * scale and float(yp.abs().max()) < 1e-10 * scale
+    # (3)
+    g0 = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=u.device)
+    f0 = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=u.device)
+    l3 = asm.new_linsys()
+    assert asm.adjoint_jacobian(u, p, z, zp, xi0, xi, g0, f0, l3) == 0
+    del g0, f0
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda t: torch.randn(t.shape, generator=gen, dtype=torch.float64).to(u.device)
+    dot = lambda a, b: float((a * b).sum())
+    xu, xp, yu, yp = rnd(u), rnd(p), rnd(u), rnd(p)
+    a3u, a3p, a1u, a1p = torch.zeros_like(u), torch.zeros_like(p), torch.zeros_like(u), torch.zeros_like(p)
+    asm.apply_A(l3, xu, xp, a3u, a3p)
+    asm.apply_A(l1, yu, yp, a1u, a1p)
+    lhs, rhs = dot(yu, a3u) + dot(yp, a3p), dot(xu, a1u) + dot(xp, a1p)
+    assert abs(lhs - rhs) < 1e-12 * float(a3u.abs().max()) * float(yu.abs().sum()), (lhs, rhs)
+    del l1, l3, a3u, a3p, a1u, a1p
+    # (4) sampled elements, each as a mesh of its own with 8 private nodes: assembled on the device and by the oracle
+    rng = np.random.default_rng(12)
+    sample = np.sort(rng.choice(asm.nelems, 200, replace=False))
+    nodes = conn[sample].ravel()
+    sc, sconn = np.ascontiguousarray(coords[nodes]), np.arange(len(nodes), dtype=np.int32).reshape(-1, 8)
+    su = np.ascontiguousarray(u_h.reshape(-1, 3)[nodes].ravel())
+    sp_ = np.ascontiguousarray(p_h[nodes])
+    orc = ol.Oracle(ol.HEX8, sc, sconn, "small_J2", J2)
+    small = Assembler(8, sc, sconn, "small_J2", J2)
+    lo, xo = orc.new_linsys(), orc.new_state()
+    assert orc.forward_jacobian(su, sp_, 0 * su, 0 * sp_, orc.new_state(), xo, lo) == 0
+    ls, xs = small.new_linsys(), small.new_state()
+    assert small.forward_jacobian(small.dev(su), small.dev(sp_), small.dev(0 * su), small.dev(0 * sp_), small.new_state(), xs, ls) == 0
+    assert rel_vec(xs.cpu().numpy(), xo) < 1e-12
+    assert rel_vec(xi.cpu().numpy()[sample], xo) < 1e-12   # the full-size run's states of those elements
+    for i in range(2):
+        assert rel_vec(ls.b[i].cpu().numpy(), lo.b[i]) < 1e-12
+        for j in range(2):
+            assert rel_vec(ls.A[i][j].cpu().numpy(), lo.A[i][j]) < 1e-12

@@ -18,6 +18,7 @@ timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.e
 echo bench default done
 timeout -k 10 200 python3 bench.py --no-cpu --scatter atomic > $O/bench_atomic.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scatter colored > $O/bench_colored.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu --workload notch > $O/bench_notch.json 2>/dev/null || exit 1
 echo bench modes done
 timeout -k 10 300 python3 tools/bench_kernels.py > $O/kernels_small_J2.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model hyper_J2 > $O/kernels_hyper_J2.json 2>/dev/null || exit 1

@@ -29,6 +29,7 @@ for mode in ("atomic", "gather"):
 put("bench_default.json", "bench_default_wave_gather_100cube.json")
 put("bench_atomic.json", "bench_wave_atomic_100cube.json")
 put("bench_colored.json", "bench_wave_colored_100cube.json")
+put("bench_notch.json", "bench_notch_specimen_1M.json")
 put("fractions.json", "plastic_fractions_100cube.json")
 for m in ("small_J2", "hyper_J2", "small_hill", "hypo_hill"):
     put("kernels_%s.json" % m, "all_kernels_%s_100cube.json" % m)
