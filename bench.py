@@ -400,6 +400,13 @@ def main():
         if prof:
             out["roofline"]["valu"] = valu_utilisation(prof, kernel_ms)
             out["roofline"]["traffic_profile"] = prof["file"]
+            if prof.get("traffic_bytes_per_launch"):
+                # beside the contract's fraction (algorithmic bytes / time / peak): the rate at which the kernels really
+                # move their HBM bytes, and how many bytes they move per algorithmic byte
+                tr = float(prof["traffic_bytes_per_launch"])
+                out["roofline"]["traffic_rate"] = {"GB_per_s": tr / (kernel_ms * 1e-3) / 1e9,
+                                                   "frac_of_peak": tr / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   "bytes_per_algorithmic_byte": tr / balg}
         elif prof_other:
             out["roofline"]["profile_of_another_build"] = {
                 "file": prof_other["file"], "build_id": prof_other.get("build_id"),
