@@ -8,4 +8,4 @@ in HBM.  There is no CPU execution path: creating an `Assembler` without a HIP d
 from .lib import C8Error, load_library  # noqa: F401
 from .assembly import Assembler, LinearSystem, brick_mesh, brick_partition  # noqa: F401
 from .primal import PrimalDriver, adjoint_gradient, scipy_solver  # noqa: F401
-from .inverse import InverseProblem, lbfgs_minimize  # noqa: F401
+from .inverse import FEMUProblem, InverseProblem, lbfgs_minimize  # noqa: F401

@@ -59,7 +59,10 @@ class InverseProblem:
 
     def __init__(self, make_primal, base_params, active, bounds, comm=None):
         self.comm = comm
-        self.make_primal = make_primal
+        # one forward problem, or several that share the parameters (the "problems" of the reference's input,
+        # objective.cpp:16-39: J and the gradient are summed over them)
+        self.problems = list(make_primal) if isinstance(make_primal, (list, tuple)) else [make_primal]
+        self.make_primal = self.problems[0]
         self.base = np.array(base_params, dtype=np.float64)
         self.active = [int(a) for a in active]
         b = np.asarray(bounds, dtype=np.float64)
@@ -88,18 +91,21 @@ class InverseProblem:
         phys = self.to_physical(canonical)
         params = self.base.copy()
         params[self.active] = phys
-        try:
-            pr = self.make_primal(params)
-        except (RuntimeError, _l.C8Error):
-            pr = None  # the forward problem failed at these parameters (adjoint_objective.cpp lets ROL back off)
-        if self.comm is not None:  # every part backs off together
-            if self.comm.allreduce(np.array([0.0 if pr is not None else 1.0]))[0] > 0.0:
+        J, g = 0.0, np.zeros(len(self.active))
+        for make in self.problems:
+            try:
+                pr = make(params)
+            except (RuntimeError, _l.C8Error):
+                pr = None  # the forward problem failed at these parameters (adjoint_objective.cpp lets ROL back off)
+            if self.comm is not None:  # every part backs off together
+                if self.comm.allreduce(np.array([0.0 if pr is not None else 1.0]))[0] > 0.0:
+                    return None
+            elif pr is None:
                 return None
-        elif pr is None:
-            return None
-        pr.asm.set_active(0, self.active)
-        J = pr.qoi()
-        g = np.ascontiguousarray(adjoint_gradient(pr, len(self.active)))
+            pr.asm.set_active(0, self.active)
+            J += pr.qoi()
+            g += np.ascontiguousarray(adjoint_gradient(pr, len(self.active)))
+            del pr
         if self.comm is not None:
             red = self.comm.allreduce(np.concatenate([[J], g]))
             J, g = float(red[0]), np.ascontiguousarray(red[1:])
@@ -115,3 +121,59 @@ class InverseProblem:
         x0 = self.to_canonical(initial_active)
         x, info = lbfgs_minimize(self.value_and_gradient, x0, -1.0, 1.0, **opts)
         return self.to_physical(x), info
+
+
+class FEMUProblem(InverseProblem):
+    """FEMU_Objective (femu_objective.cpp:13-36): the value is the same sum over problems and steps of eval_qoi after the
+    primal solves, kept for the last parameter vector (`param_diff`, objective.cpp:139-151); there is no adjoint -- the
+    reference leaves the gradient to the optimiser's finite differences, restated here as forward differences of the
+    value in the canonical variables (step `fd_step` times max(1, |x_i|), stepping inwards at the upper bound)."""
+
+    def __init__(self, make_primal, base_params, active, bounds, comm=None, fd_step=1e-6):
+        super().__init__(make_primal, base_params, active, bounds, comm)
+        self.fd_step = float(fd_step)
+        self._last = (None, None)
+
+    def value(self, canonical):
+        canonical = np.ascontiguousarray(canonical, dtype=np.float64)
+        if self._last[0] is not None and np.array_equal(self._last[0], canonical):
+            return self._last[1]
+        params = self.base.copy()
+        params[self.active] = self.to_physical(canonical)
+        J = 0.0
+        for make in self.problems:
+            try:
+                pr = make(params)
+            except (RuntimeError, _l.C8Error):
+                pr = None
+            if self.comm is not None:
+                if self.comm.allreduce(np.array([0.0 if pr is not None else 1.0]))[0] > 0.0:
+                    return None
+            elif pr is None:
+                return None
+            J += pr.qoi()
+            del pr
+        if self.comm is not None:
+            J = float(self.comm.allreduce(np.array([J]))[0])
+        self._last = (canonical.copy(), J)
+        return J
+
+    def value_and_gradient(self, canonical):
+        canonical = np.ascontiguousarray(canonical, dtype=np.float64)
+        J = self.value(canonical)
+        if J is None:
+            return None
+        g = np.zeros_like(canonical)
+        for i in range(len(canonical)):
+            h = self.fd_step * max(1.0, abs(canonical[i]))
+            if canonical[i] + h > 1.0:
+                h = -h
+            x = canonical.copy()
+            x[i] += h
+            Jh = self.value(x)
+            if Jh is None:
+                return None
+            g[i] = (Jh - J) / h
+        self._last = (canonical.copy(), J)
+        self.history.append((self.to_physical(canonical), float(J)))
+        return J, g

@@ -176,6 +176,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError("calibr8_amd/libc8.so is missing: run `python -m calibr8_amd.build` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        # This Python layer keeps its arrays in torch tensors, and the torch wheel carries a HIP runtime of its own: it has
+        # to be the one libc8.so binds to.  Loaded the other way round (libc8.so first, torch afterwards) the process ends
+        # up with two runtimes and c8_create finds no device.  (A C or C++ host links libc8.so against its own runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)

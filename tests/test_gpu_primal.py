@@ -295,6 +295,42 @@ def test_device_inverse_problem_recovers_parameters():
     assert np.abs(found / truth[active] - 1.0).max() < 1e-3, (found, info)
 
 
+def test_femu_objective_and_several_problems_on_device():
+    # FEMU_Objective (femu_objective.cpp:13-36): the value of the adjoint objective without its gradient -- finite
+    # differences of it reproduce the adjoint gradient; two forward problems sharing the parameters (objective.cpp:16-39)
+    # add their objectives and gradients; the value is kept for the last parameter vector (param_diff)
+    from calibr8_amd import Assembler, FEMUProblem, InverseProblem, PrimalDriver
+    c, conn, sets = brick(3, 3, 2, 1.0, 1.2, 1.0)
+    zero = lambda x, y, z, t: 0.0
+    calls = [0]
+
+    def problem(rate):
+        spec = [(0, 0, sets["xmin"], zero), (0, 1, sets["ymin"], zero), (0, 2, sets["zmin"], zero),
+                (0, 1, sets["ymax"], lambda x, y, z, t: rate * t)]
+
+        def make(params):
+            calls[0] += 1
+            return PrimalDriver(Assembler(8, c, conn, "small_J2", params), spec, max_iters=20, abs_tol=1e-12, rel_tol=1e-12).solve(2)
+        return make
+
+    truth, active, bounds = np.array(J2), [2, 3], [[50.0, 200.0], [1.0, 4.0]]
+    adj = InverseProblem(problem(0.003), truth, active, bounds)
+    femu = FEMUProblem(problem(0.003), truth, active, bounds, fd_step=1e-6)
+    # (trial parameters away from the load at which the uniform bar reaches the yield surface: J has a kink there)
+    x = adj.to_canonical(np.array([120.0, 2.2]))
+    J_a, g_a = adj.value_and_gradient(x)
+    J_f, g_f = femu.value_and_gradient(x)
+    assert abs(J_f - J_a) < 1e-14 * abs(J_a)
+    assert np.abs(g_f - g_a).max() < 1e-4 * np.abs(g_a).max(), (g_f, g_a)
+    n = calls[0]
+    assert femu.value(x) == J_f and calls[0] == n   # same parameters: no new forward solve
+    both = InverseProblem([problem(0.003), problem(0.002)], truth, active, bounds)
+    other = InverseProblem(problem(0.002), truth, active, bounds)
+    J_b, g_b = both.value_and_gradient(x)
+    J_o, g_o = other.value_and_gradient(x)
+    assert abs(J_b - (J_a + J_o)) < 1e-13 * abs(J_b) and np.abs(g_b - (g_a + g_o)).max() < 1e-12 * np.abs(g_b).max()
+
+
 def test_baseline_config1_hex8_elastic_bar_on_device():
     # BASELINE.json configs[0]: the 10^3 hex8 elastic bar, solved with the device Newton driver
     from calibr8_amd import Assembler, PrimalDriver
