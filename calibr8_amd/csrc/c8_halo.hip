@@ -91,10 +91,18 @@ Rccl& rccl() {
   names.push_back("librccl.so.1");
   names.push_back("librccl.so");
   names.push_back("/opt/rocm/lib/librccl.so.1");
-  for (auto const& n : names) {
-    r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (r.lib) break;
-  }
+  // a copy the process has loaded already comes first (under PyTorch that is the one built against the HIP runtime in
+  // the process; loading a second RCCL beside it would give the process two)
+  if (!std::getenv("C8_RCCL_LIB"))
+    for (char const* n : {"librccl.so", "librccl.so.1"}) {
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      if (r.lib) break;
+    }
+  if (!r.lib)
+    for (auto const& n : names) {
+      r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
   if (!r.lib) { r.error = std::string("cannot load librccl (set C8_RCCL_LIB): ") + dlerror(); return r; }
   auto sym = [&](char const* name) -> void* {
     void* p = dlsym(r.lib, name);
