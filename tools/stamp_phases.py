@@ -12,10 +12,13 @@ import torch
 from calibr8_amd import Assembler, brick_mesh
 from meshes import prescribed_fields
 
-J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
+from parity_cases import HILL, HJ2, J2
+model = os.environ.get("MODEL", "small_J2")  # MODEL=hyper_J2 | small_hill | hypo_hill: the iterated kernel of that model
 n = 100
 coords, conn = brick_mesh(n, n, n)
-asm = Assembler(8, coords, conn, "small_J2", J2, scatter=sys.argv[1] if len(sys.argv) > 1 else "atomic")
+asm = Assembler(8, coords, conn, model, {"small_J2": J2, "hyper_J2": HJ2, "small_hill": HILL, "hypo_hill": HILL}[model],
+                scatter=sys.argv[1] if len(sys.argv) > 1 else "atomic")
+asm.set_kernel("wave_ad")  # the stamps sit in the iterated kernel
 u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
 u, p = asm.dev(u_h), asm.dev(p_h)
 u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
@@ -31,7 +34,7 @@ asm.L.c8_debug_stamps(asm.h, buf.ctypes.data_as(C.c_void_p))
 raw = buf.reshape(4096, 16)[:, [0, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8, 9]].astype(np.int64)  # stamps in program order
 d = np.diff(raw, axis=1)
 names = ["loads (conn, then nodal)", "shape tables", "interpolation", "newton", "inverse", "D pass0", "P pass0", "D pass1", "P pass1", "(loop end)", "scatter"]
-plastic = (xi[::244][:4096, :, 6] > 0).any(dim=1).cpu().numpy()
+plastic = (xi[::244][:4096, :, -1] > 0).any(dim=1).cpu().numpy()
 ok = raw[:, 11] > raw[:, 0]
 raw, d, plastic = raw[ok], d[ok], plastic[ok]
 for label, sel in (("all", np.ones(len(raw), bool)), ("elastic elems", ~plastic), ("plastic elems", plastic)):
