@@ -346,6 +346,8 @@ def main():
     halo_bytes = int(hb.item())
     nelems_total = int(ne.item())
     value = nelems_total * args.steps / dt
+    if "ms_per_step_iterated_ad_form" in also:  # the same metric for the iterated AD form (whole job, elements per second)
+        also["elements_per_s_iterated_ad_form"] = nelems_total / (1e-3 * also["ms_per_step_iterated_ad_form"])
     plastic_frac = float((xi[:, :, 6] > 0).double().mean().item())
     build_info = c8lib.load_library().c8_build_info().decode()
     build_id = build_info.split()[0].split("=")[1]
