@@ -32,10 +32,14 @@ def free_port():
     return p
 
 
-def global_problem(n):
-    from meshes import brick, jiggle, prescribed_fields
-    c, conn, sets = brick(n[0], n[1], n[2], 1.0, 0.8, 0.7)
-    c = jiggle(c, sets, 0.03)
+def global_problem(n, notch=False):
+    from meshes import brick, jiggle, notched_bar, prescribed_fields
+    if notch:  # BASELINE config 3's geometry: node degrees vary, the parts are slabs along the bar
+        c, conn, sets = notched_bar(n[0], n[1], n[2])
+        c = jiggle(c, sets, 0.01)
+    else:
+        c, conn, sets = brick(n[0], n[1], n[2], 1.0, 0.8, 0.7)
+        c = jiggle(c, sets, 0.03)
     u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
     return c, conn, u, p
 
@@ -47,8 +51,13 @@ def worker(rank, world, port, n, pdims, use_brick_part, out):
         import oracle_lib as ol
         from calibr8_amd import distributed as D
         from calibr8_amd.lib import load_library
-        c, conn, u, p = global_problem(n)
-        if use_brick_part:
+        c, conn, u, p = global_problem(n, notch=(use_brick_part == "notch"))
+        if use_brick_part == "notch":  # slabs of equal element counts along the bar (bench.py --workload notch)
+            order = np.argsort(c[conn].mean(axis=1)[:, 0], kind="stable")
+            ep = np.empty(len(conn), dtype=np.int32)
+            ep[order] = (np.arange(len(conn)) * world) // len(conn)
+            part = D.part_from_global(c, conn, ep, rank, world)
+        elif use_brick_part:
             assert n[0] == n[1] == n[2]
             part = D.brick_part(rank, pdims, n[0] // pdims[0], edge=1.0)  # analytic partition, un-jiggled coords
             from meshes import brick, prescribed_fields
@@ -61,7 +70,7 @@ def worker(rank, world, port, n, pdims, use_brick_part, out):
             L.c8_brick_partition(n[0], n[1], n[2], pdims[0], pdims[1], pdims[2], ep.ctypes.data_as(C.POINTER(C.c_int32)))
             part = D.part_from_global(c, conn, ep, rank, world)
         plan = D.HaloPlan(part, dist)
-        if use_brick_part:
+        if use_brick_part is True:
             assert np.allclose(plan.coords, c[plan.node_gid], atol=1e-12)
         lc = c[plan.node_gid]
         orc = ol.Oracle(ol.HEX8, lc, part.conn, "small_J2", J2, extra_pairs=plan.extra_pairs)
@@ -150,6 +159,12 @@ def test_two_parts_gloo():
 
 def test_four_parts_gloo():
     run(4, (6, 6, 3), (2, 2, 1))
+
+
+def test_notched_specimen_parts_gloo():
+    # the notched specimen cut into three slabs along the bar: ghost rows added into their owners and the owned system
+    # against the single-part assembly of the whole specimen, phantom columns, owner -> copy import, packed all-reduce
+    run(3, (18, 8, 4), (3, 1, 1), use_brick_part="notch")
 
 
 def test_eight_analytic_brick_parts_gloo():
