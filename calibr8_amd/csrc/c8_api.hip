@@ -144,7 +144,7 @@ int c8_create(const c8_mesh_desc* md, const c8_model_desc* mo, c8_ctx** out) {
   c->ms = ModelSettings{mo->stabilization_multiplier, mo->local_abs_tol, mo->local_rel_tol, mo->local_max_iters,
                         mo->thickness > 0. ? mo->thickness : 1.};
   c->nres = model_is_plane_stress(model) ? 1 : 2;
-  c->ms.closed_form = c->ms.max_iters >= 8 ? 1 : 0;  // see c8_set_kernel_variant
+  c->ms.closed_form = c->ms.closed_form_slot = c->ms.max_iters >= 8 ? 1 : 0;  // see c8_set_kernel_variant
   if (mo->ls_max_evals < 0 || mo->ls_sufficient_decrease < 0. || mo->ls_min_backtrack < 0. || mo->ls_max_backtrack < 0.) {
     delete c;
     return fail(C8_ERR_ARG, "c8_create: negative line-search setting");
@@ -344,6 +344,7 @@ int c8_set_kernel_variant(c8_ctx* c, int variant) {
   // a model's closed form (small_J2) runs in the forward wave kernel unless the caller asks for the iterated AD form or
   // gives the local Newton iteration a budget in which it may fail: the failure (-1) is the iterated form's to report
   c->ms.closed_form = (variant != C8_KERNEL_WAVE_AD && c->ms.max_iters >= 8) ? 1 : 0;
+  c->ms.closed_form_slot = (variant == C8_KERNEL_AUTO && c->ms.max_iters >= 8) ? 1 : 0;  // an explicit C8_KERNEL_SLOT iterates
   return C8_OK;
 }
 #ifdef C8_STAMPS

@@ -54,6 +54,7 @@ struct ModelSettings {
   double ls_c1 = 1.e-4, ls_bmin = 0.5, ls_bmax = 0.9;
   int ls_max_evals = 4;
   int closed_form = 0;  // forward wave kernel: the model's closed form where it has one (c8_set_kernel_variant)
+  int closed_form_slot = 0;  // the same in the lane-group kernel (C8_KERNEL_AUTO only: an explicit C8_KERNEL_SLOT iterates)
 };
 struct FieldArgs {
   double const* u;        // [nnodes][3]
@@ -573,7 +574,12 @@ C8_HD void local_newton_line_search(EX& ex, SH& sh, ModelSettings const& ms) {
 // =====================================================================================
 // K1: eval_forward_jacobian (evaluations.cpp:12-154) for one element.
 // =====================================================================================
-template <class E, template <class> class ModelT, class EX>
+template <class M, class = void> struct has_closed_form : std::false_type {};
+template <class M> struct has_closed_form<M, std::enable_if_t<M::HAS_CLOSED_FORM>> : std::true_type {};
+
+// CLOSED: the instantiation that runs a model's closed form (Model::HAS_CLOSED_FORM) in place of the local Newton iteration
+// and the AD passes of the first ip set -- a kernel of its own, so that neither form carries the other's registers
+template <class E, template <class> class ModelT, bool CLOSED = false, class EX>
 C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& sh, MeshTables const& mt,
                                     ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
   using Model = ModelT<Dual>;
@@ -597,7 +603,59 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
     if (ip_set == 0 || !E::SAME_POINTS) shape_tables<E>(ex, sh, ip_set);
     int const npts = ip_set == 0 ? E::NP0 : E::NP1;
     for (int pt = 0; pt < npts; ++pt) {
+      if constexpr (CLOSED) if (ip_set == 0) {
+        // the model's closed form (Model::closed_form: converged state, fluxes and what the consistent tangent needs) in
+        // place of the local Newton iteration and the two AD passes; every lane of the group evaluates it (the values are
+        // replicated over the group as in the iterated form) and takes the column of its own element unknown from it
+        // (Model::closed_form_flux_column).  The pressure term of the second ip set stays with that set's loop below.
+        if constexpr (has_closed_form<Model>::value) {
+          size_t const q = ((size_t)e * E::NP0 + pt) * NL;
+          ex.each([&](int k) {
+            Lane& r = ex.lane(k);
+            interpolate_values<E, Dual, PREV>(sh, pt, r.g);
+            double const qv[16] = {r.g.grad_u.xx.v, r.g.grad_u.xy.v, r.g.grad_u.xz.v, r.g.grad_u.yx.v, r.g.grad_u.yy.v,
+                                   r.g.grad_u.yz.v, r.g.grad_u.zx.v, r.g.grad_u.zy.v, r.g.grad_u.zz.v, r.g.p.v,
+                                   r.g.grad_p[0].v, r.g.grad_p[1].v, r.g.grad_p[2].v, r.g.u[0].v, r.g.u[1].v, r.g.u[2].v};
+            double xo[NL];
+            C8_UNROLL
+            for (int j = 0; j < NL; ++j) xo[j] = fa.xi_prev[q + j];
+            int const es = mt.elem_set ? mt.elem_set[e] : 0;
+            typename Model::ClosedForm cf;
+            Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, qv, xo, ms.abs_tol, sh.h, ms.stab_mult, cf, false);
+            if (k == 0) {
+              C8_UNROLL
+              for (int j = 0; j < NL; ++j) fa.xi[q + j] = cf.xi[j];
+            }
+            int ik, nk, eqk;
+            slot_to_dof<E>(k, ik, nk, eqk);
+            double const w = sh.wdv[pt];
+            double const ek[3] = {(ik == 0 && eqk == 0) ? 1. : 0., (ik == 0 && eqk == 1) ? 1. : 0., (ik == 0 && eqk == 2) ? 1. : 0.};
+            double const isp = ik == 1 ? 1. : 0.;
+            double const b0 = sh.dN[pt][nk][0], b1 = sh.dN[pt][nk][1], b2 = sh.dN[pt][nk][2], bN = sh.N[pt][nk];
+            double const gk[3] = {w * b0, w * b1, w * b2};
+            double db[13];
+            Model::closed_form_flux_column(cf.t, ek, isp, gk, w * bN, db);
+            constexpr int D = E::DIM;
+            C8_UNROLL
+            for (int n = 0; n < E::NN; ++n) {
+              double const a0 = sh.dN[pt][n][0], a1 = sh.dN[pt][n][1], a2 = sh.dN[pt][n][2], aN = sh.N[pt][n];
+              r.Jcol[D * n + 0] = fma(a2, db[2], fma(a1, db[1], fma(a0, db[0], r.Jcol[D * n + 0])));
+              r.Jcol[D * n + 1] = fma(a2, db[5], fma(a1, db[4], fma(a0, db[3], r.Jcol[D * n + 1])));
+              r.Jcol[D * n + 2] = fma(a2, db[8], fma(a1, db[7], fma(a0, db[6], r.Jcol[D * n + 2])));
+              r.Jcol[D * E::NN + n] = fma(aN, db[9], fma(a2, db[12], fma(a1, db[11], fma(a0, db[10], r.Jcol[D * E::NN + n]))));
+            }
+            double const* F = cf.F;
+            // (selects, not an index: a register array indexed at run time would live in scratch memory)
+            double const r0 = F[0] * b0 + F[1] * b1 + F[2] * b2;
+            double const r1 = F[3] * b0 + F[4] * b1 + F[5] * b2;
+            double const r2 = F[6] * b0 + F[7] * b1 + F[8] * b2;
+            double const rp = F[9] * bN + F[10] * b0 + F[11] * b1 + F[12] * b2;
+            r.Rk += w * (ik == 1 ? rp : (eqk == 0 ? r0 : (eqk == 1 ? r1 : r2)));
+          });
+        }
+      }
       if (ip_set == 0) {
+        if constexpr (!CLOSED) {
         size_t const q = ((size_t)e * E::NP0 + pt) * NL;
         // --- local->gather, seed_wrt_xi, solve_nonlinear (small_J2.cpp:122-173) ---
         ex.each([&](int k) {
@@ -683,6 +741,7 @@ C8_HD void forward_jacobian_element(EX& ex, GroupShared<E, ModelT<Dual>::NLOC>& 
           global_flux<E>(r.m, r.g, sh.h, ms, f);
           accumulate_coupled<E>(sh, pt, k, f, r.Jcol, r.Rk);
         });
+        }  // !CLOSED
       } else if constexpr (E::NRES == 2) {
         ex.each([&](int k) {
           Lane& r = ex.lane(k);

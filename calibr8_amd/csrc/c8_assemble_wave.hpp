@@ -625,7 +625,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       if (d != 0) return;
       int const es = mt.elem_set ? mt.elem_set[e] : 0;
       typename Model::ClosedForm cf;
-      Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, sh.q[pt], sh.xip[pt], ms.abs_tol, sh.h, ms.stab_mult, cf);
+      Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, sh.q[pt], sh.xip[pt], ms.abs_tol, sh.h, ms.stab_mult, cf, true);
       size_t const q0 = ((size_t)e * E::NP0 + pt) * NL;
       C8_UNROLL
       for (int j = 0; j < NL; ++j) fa.xi[q0 + j] = cf.xi[j];
@@ -1049,8 +1049,6 @@ C8_HD void forward_jacobian_wave_closed(EX& ex, SH& sh, MeshTables const& mt,
                                         ModelSettings const& ms, FieldArgs const& fa, SystemArgs const& sa, int e) {
   jacobian_wave<E, ModelT, PointQoi, false, true>(ex, sh, mt, ms, fa, AdjointArgs{}, sa, e);
 }
-template <class M, class = void> struct has_closed_form : std::false_type {};
-template <class M> struct has_closed_form<M, std::enable_if_t<M::HAS_CLOSED_FORM>> : std::true_type {};
 
 template <class E, template <class> class ModelT, class QoI, class EX, class SH>
 C8_HD void adjoint_jacobian_wave(EX& ex, SH& sh, MeshTables const& mt,

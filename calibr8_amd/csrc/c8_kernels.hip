@@ -142,12 +142,39 @@ __global__ void __launch_bounds__(BLOCK) k_forward_jacobian(MeshTables mt, Model
   forward_jacobian_element<E, ModelT>(ex, shs[gib], mt, ms, fa, sa, e);
 }
 
+// K1 in lane groups with the model's closed form (Model::HAS_CLOSED_FORM) in place of the local Newton iteration and the AD
+// passes of the first ip set
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_forward_jacobian_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, SystemArgs sa,
+                                                                 int first, int count, int nblocks) {
+  constexpr int GPB = BLOCK / E::NDOF;
+  using Lane = ForwardLane<E, ModelT>;
+  __shared__ GroupShared<E, ModelT<Dual>::NLOC> shs[GPB];
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks) return;
+  int const gib = threadIdx.x / E::NDOF, k = threadIdx.x % E::NDOF;
+  if (gib >= GPB) return;
+  int const gi = lb * GPB + gib;
+  if (gi >= count) return;
+  int const e = mt.order ? mt.order[first + gi] : first + gi;
+  Lane L;
+  GpuExec<Lane> ex(k, L);
+  forward_jacobian_element<E, ModelT, true>(ex, shs[gib], mt, ms, fa, sa, e);
+}
+
 template <class E, template <class> class ModelT>
 static hipError_t launch_forward(LaunchArgs const& a) {
   constexpr int GPB = BLOCK / E::NDOF;
   int const nblocks = (a.count + GPB - 1) / GPB;
   int const grid = ((nblocks + 7) / 8) * 8;
   if (a.count <= 0) return hipSuccess;
+  if constexpr (has_closed_form<ModelT<Dual>>::value) {
+    if (a.ms.closed_form_slot) {
+      hipLaunchKernelGGL((k_forward_jacobian_closed<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
+                         a.first, a.count, nblocks);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((k_forward_jacobian<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.sa,
                      a.first, a.count, nblocks);
   return hipGetLastError();

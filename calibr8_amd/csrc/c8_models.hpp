@@ -222,8 +222,10 @@ template <class T, int DIM> struct SmallJ2Dim {
     double t[NT];      // what the tangent columns need: a, b, tr(n)/3, 1/kappa, tau, n (9)
   };
   // once per point (the kernel runs it on one lane per point and hands t to the lanes that write the columns)
+  // pressure_mass: the -p / kappa term of the pressure residual (Mechanics::flux_pressure) rides along -- the wave kernel
+  // fuses the two ip sets of hex8; the lane-group kernels leave it to the loop over the second ip set
   C8_HD static void closed_form(double const* prm, double const* q, double const* xi_old, double abs_tol, double h,
-                                double stab_mult, ClosedForm& cf) {
+                                double stab_mult, ClosedForm& cf, bool pressure_mass) {
     double const sqrt_23 = 0.81649658092772603273;
     double const E = prm[0], nu = prm[1], K = prm[2], Y = prm[3];
     double const mu = E * c8_rcp(2. * (1. + nu)), kappa = E * c8_rcp(3. * (1. - 2. * nu));
@@ -273,13 +275,13 @@ template <class T, int DIM> struct SmallJ2Dim {
     cf.t[0] = (2. * mu) * theta;
     double const inv_kappa = c8_rcp(kappa);
     double const tau = (stab_mult * 0.5 * h * h) * inv_mu;
-    cf.t[3] = inv_kappa;
+    cf.t[3] = pressure_mass ? inv_kappa : 0.;
     cf.t[4] = tau;
     double const p = q[9];
     C8_UNROLL
     for (int k = 0; k < 9; ++k) cf.F[k] = theta * st[k] - ((k == 0 || k == 4 || k == 8) ? p : 0.);
     double const hydro = kappa * tr - prm[4] * prm[5] * E * c8_rcp(1. - 2. * nu);
-    cf.F[9] = -(hydro * inv_kappa) + -(p * inv_kappa);
+    cf.F[9] = pressure_mass ? -(hydro * inv_kappa) + -(p * inv_kappa) : -(hydro * inv_kappa);
     cf.F[10] = -(tau * q[10]); cf.F[11] = -(tau * q[11]); cf.F[12] = -(tau * q[12]);
   }
   // (d flux / d q)(d q / d x_b) for one element unknown x_b, 13 entries: x_b = u_k of a node (ek = e_k, isp = 0) or p of a

@@ -176,10 +176,12 @@ int c8_set_shape_cache(c8_ctx* ctx, int on);
 /* Forward-assembly kernel: C8_KERNEL_SLOT = one lane group per element (any element type);
  * C8_KERNEL_WAVE = one wavefront per element (hex8); C8_KERNEL_AUTO picks WAVE where available.  Where a model has a
  * closed form of its local equations (small_J2 on 3-D meshes: radial return and consistent tangent), the forward WAVE
- * kernel uses it in place of the local Newton iteration and the automatic-differentiation passes: the same converged
- * state and Jacobian as the iterated form to within the local Newton tolerance (2e-13 measured).  C8_KERNEL_WAVE_AD keeps the iterated, automatically differentiated
- * form in every kernel; it also runs whenever local_max_iters < 8, so that a local solve that cannot converge within
- * the caller's budget still reports C8_LOCAL_SOLVE_FAILED as the reference does. */
+ * kernel -- and, under C8_KERNEL_AUTO, the lane-group kernel of an element type without a wave kernel (tet4) -- uses it
+ * in place of the local Newton iteration and the automatic-differentiation passes: the same converged state and
+ * Jacobian as the iterated form to within the local Newton tolerance (2e-13 measured).  C8_KERNEL_WAVE_AD (hex8) and an
+ * explicit C8_KERNEL_SLOT keep the iterated, automatically differentiated form; it also runs whenever
+ * local_max_iters < 8, so that a local solve that cannot converge within the caller's budget still reports
+ * C8_LOCAL_SOLVE_FAILED as the reference does. */
 int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 /* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
  * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */

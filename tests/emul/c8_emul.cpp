@@ -154,8 +154,14 @@ template <class E, template <class> class ModelT> static void run(Call const& c)
   SH sh;
   if (c.what == K_FORWARD) {
     auto* ex = new CpuExec<ForwardLane<E, ModelT>, E::NDOF>();
-    if (c.staged) run_staged<E>(c, [&](SystemArgs const& sa, int e) { forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, sa, e); });
-    else for (int e = 0; e < c.nelems; ++e) forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, c.sa, e);
+    auto fwd = [&](SystemArgs const& sa, int e) {  // the library's launcher: the closed-form instantiation where the model has one
+      if constexpr (has_closed_form<ModelT<Dual>>::value) {
+        if (c.ms.closed_form_slot) { forward_jacobian_element<E, ModelT, true>(*ex, sh, c.mt, c.ms, c.fa, sa, e); return; }
+      }
+      forward_jacobian_element<E, ModelT>(*ex, sh, c.mt, c.ms, c.fa, sa, e);
+    };
+    if (c.staged) run_staged<E>(c, fwd);
+    else for (int e = 0; e < c.nelems; ++e) fwd(c.sa, e);
     delete ex;
   } else if (c.what == K_RESIDUAL) {
     auto* ex = new CpuExec<ResidualLane<E, ModelT>, E::NDOF>();
@@ -370,6 +376,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
     c.mt.shape = shape_tab.data();
   }
   c.ms = ModelSettings{stab_mult, abs_tol, rel_tol, max_iters};
+  c.ms.closed_form_slot = c.closed;  // the lane-group kernel's closed-form path (the library: C8_KERNEL_AUTO)
   c.ms.ls_c1 = g_ls_c1; c.ms.ls_bmin = g_ls_bmin; c.ms.ls_bmax = g_ls_bmax; c.ms.ls_max_evals = g_ls_max_evals;
   c.fa = FieldArgs{ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]};
   c.sa = SystemArgs{{{ptrs[6], ptrs[7]}, {ptrs[8], ptrs[9]}}, {ptrs[10], ptrs[11]}, &status, 0};

@@ -70,6 +70,8 @@ def main():
     for k in variants:
         asm.set_kernel(k)
         res["forward_jacobian_" + k] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))
+    asm.set_kernel("auto")  # the library's choice (a model's closed form where it has one)
+    res["forward_jacobian_auto"] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))
     for k in variants:
         asm.set_kernel(k)
         res["adjoint_jacobian_" + k] = timeit(lambda: asm.adjoint_jacobian(u, p, u0, p0, xi0, xi, g, f, ls))
