@@ -373,6 +373,49 @@ def test_closed_form_against_iterated_form(params):
         assert np.array_equal(a, a2)  # staged assembly: bitwise reproducible, and "wave" is the default form again
 
 
+@pytest.mark.parametrize("scatter", ["gather", "atomic"])
+def test_closed_form_against_iterated_form_tet4(scatter):
+    # the lane-group kernel's two instantiations on a tet mesh (the reference's element type): C8_KERNEL_AUTO runs small_J2's
+    # closed form, an explicit C8_KERNEL_SLOT the local Newton iteration with the AD passes -- same state, residual and
+    # Jacobian to the local Newton tolerance over two load steps, the second from a plastic state; a context whose local
+    # Newton budget is below eight iterations always iterates
+    from gpu_backend import GpuBackend
+    from calibr8_amd import brick_mesh
+    from parity_cases import mesh_of
+    et, c0, conn0 = mesh_of("tet4")
+    n = 10  # 6000 tets: every brick cell split into six
+    hc, hconn = brick_mesh(n, n, n)
+    T = np.array([[0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6], [0, 5, 1, 6]])
+    conn = np.ascontiguousarray(hconn[:, T].reshape(-1, 4).astype(np.int32))
+    X = hc[conn]
+    vol = np.einsum("ij,ij->i", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0])
+    conn[vol < 0] = conn[vol < 0][:, [0, 2, 1, 3]]
+    gpu = GpuBackend(ol.TET4, hc, conn, "small_J2", J2, scatter=scatter)
+    u1, p1 = prescribed_fields(hc, 0.004, ramp=True, perturb=5e-2)
+    u0, p0 = np.zeros_like(u1), np.zeros_like(p1)
+
+    def run(g, kernel):
+        g.asm.set_kernel(kernel)
+        xi0, xi1, xi2 = g.new_state(), g.new_state(), g.new_state()
+        l1, l2 = g.new_linsys(), g.new_linsys()
+        assert g.forward_jacobian(u1, p1, u0, p0, xi0, xi1, l1) == 0
+        assert g.forward_jacobian(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, l2) == 0
+        assert (xi2[:, :, 6] > xi1[:, :, 6]).any() and (xi1[:, :, 6] > 0).any() and (xi1[:, :, 6] == 0).any()
+        return [xi1, xi2] + [l.b[i] for l in (l1, l2) for i in range(2)] + \
+               [l.A[i][j] for l in (l1, l2) for i in range(2) for j in range(2)]
+
+    closed, iterated = run(gpu, "auto"), run(gpu, "slot")
+    differs = False
+    for a, b in zip(closed, iterated):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+        differs = differs or not np.array_equal(a, b)
+    assert differs  # two different kernels did run
+    few = GpuBackend(ol.TET4, hc, conn, "small_J2", J2, scatter=scatter, max_iters=6)
+    if scatter == "gather":  # (bitwise reproducible mode) the small budget selects the iterated form under AUTO too
+        for a, b in zip(run(few, "auto"), iterated):
+            assert np.array_equal(a, b)
+
+
 def test_iterated_form_needs_the_wave_kernel():
     from calibr8_amd import C8Error
     from gpu_backend import GpuBackend
