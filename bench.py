@@ -186,6 +186,11 @@ def main():
         if transport == "rccl":
             try:
                 comm = D.Comm.rccl(dist, rank, world)
+                # pre-flight: one small all-reduce through the new communicator; a wrong sum or an error sends every rank
+                # to the host transport below
+                chk = comm.allreduce(np.array([1.0, float(rank)]))
+                if abs(chk[0] - world) > 1e-12 or abs(chk[1] - 0.5 * world * (world - 1)) > 1e-9:
+                    raise RuntimeError("all-reduce through the RCCL communicator returned %r" % (chk,))
                 ok = 1.0
             except Exception as e:  # every rank must take the same branch
                 print("rank %d: RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
