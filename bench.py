@@ -104,7 +104,7 @@ def main():
                     help="gather (default): staged assembly + row sums, no atomics, bitwise reproducible, fastest")
     ap.add_argument("--cpu-sample", type=int, default=32, help="edge of the CPU-baseline sample brick")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = host cores available, max 16)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave", "wave_ad"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "slot", "wave", "wave_ad", "node"])
     ap.add_argument("--stage-overlap", type=int, default=-1, help="scatter=gather: 1 = row sums of a chunk beside the assembly of the next (second stream), 0 = one after the other; default: the library's choice")
     ap.add_argument("--stage-chunk", type=int, default=0, help="scatter=gather: minimum elements per staged chunk")
     ap.add_argument("--assign", action="store_true", help="scatter=gather: c8_set_assign_mode (zero_all + assembly in one call); "

@@ -190,7 +190,7 @@ class Assembler:
     def set_kernel(self, variant):
         """'auto' | 'slot' (one lane group per element) | 'wave' (one wavefront per hex8 element) | 'wave_ad' (the same with the
         iterated, automatically differentiated local solve also where a model has a closed form)"""
-        v = {"auto": _l.C8_KERNEL_AUTO, "slot": _l.C8_KERNEL_SLOT, "wave": _l.C8_KERNEL_WAVE, "wave_ad": _l.C8_KERNEL_WAVE_AD}[variant]
+        v = {"auto": _l.C8_KERNEL_AUTO, "slot": _l.C8_KERNEL_SLOT, "wave": _l.C8_KERNEL_WAVE, "wave_ad": _l.C8_KERNEL_WAVE_AD, "node": _l.C8_KERNEL_NODE}[variant]
         _l.check(self.L.c8_set_kernel_variant(self.h, v))
 
     def set_async(self, flag):

@@ -209,6 +209,7 @@ int c8_set_shape_cache(c8_ctx* c, int on) {
 
 void c8_destroy(c8_ctx* c) {
   if (!c) return;
+  c8_halo_detach_ctx(c);  // an attached halo outlives the context detached (c8_halo_destroy must not touch freed memory)
   stage_release(c);
   for (hipEvent_t e : c->ev_asm) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_sum) (void)hipEventDestroy(e);
@@ -331,15 +332,25 @@ int c8_gather_finish(c8_ctx* c) {
   if (!c) return fail(C8_ERR_ARG, "c8_gather_finish: null ctx");
   if (!c->gather_pending) return C8_OK;
   c->gather_pending = false;
+  if (c->pending_node_rows) {
+    c->pending_node_rows = false;
+    MeshTables const mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params, c->d_shape};
+    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, c->pending_ga, c->nr_early_count, (int)c->nr_order.size() - c->nr_early_count,
+                           c->graph.max_degree, c->stream));
+    return C8_OK;
+  }
   int const total = (int)c->plan.node_order.size();
   C8_HIP(c->ks.gather_rows(c->pending_ga, c->early_count, total - c->early_count, c->graph.max_degree, c->stream));
   if (c->async) return C8_OK;
   return c8_status(c);
 }
 int c8_set_kernel_variant(c8_ctx* c, int variant) {
-  if (!c || variant < C8_KERNEL_AUTO || variant > C8_KERNEL_WAVE_AD) return fail(C8_ERR_ARG, "c8_set_kernel_variant: bad argument");
+  if (!c || variant < C8_KERNEL_AUTO || variant > C8_KERNEL_NODE) return fail(C8_ERR_ARG, "c8_set_kernel_variant: bad argument");
   if ((variant == C8_KERNEL_WAVE || variant == C8_KERNEL_WAVE_AD) && !c->ks.forward_jacobian_wave)
     return fail(C8_ERR_UNSUPPORTED, "c8_set_kernel_variant: the wave-per-element kernels exist for hex8 elements and the models without a local line search");
+  if (variant == C8_KERNEL_NODE && (!c->ks.node_rows || c->ms.max_iters < 8))
+    return fail(C8_ERR_UNSUPPORTED, "c8_set_kernel_variant: the row-per-node kernel exists for hex8 elements and models with a closed form (small_J2), with local_max_iters >= 8");
+  if (c->gather_pending) return fail(C8_ERR_ARG, "c8_set_kernel_variant: an assembly is waiting for c8_gather_finish");
   c->kernel_variant = variant;
   // a model's closed form (small_J2) runs in the forward wave kernel unless the caller asks for the iterated AD form or
   // gives the local Newton iteration a budget in which it may fail: the failure (-1) is the iterated form's to report
@@ -402,8 +413,47 @@ static int stage_setup(c8_ctx* c) {
 static void stage_release(c8_ctx* c) {
   (void)hipFree(c->d_stage);
   (void)hipFree(c->d_node_order);
+  (void)hipFree(c->d_nr_order);
   c->d_stage = nullptr;
   c->d_node_order = nullptr;
+  c->d_nr_order = nullptr;
+}
+
+// Row-per-node forward assembly (c8_assemble_node.hpp): whether this call takes it, and its launches.
+static bool node_rows_applies(c8_ctx const* c, FieldArgs const& fa) {
+  return c->ks.node_rows && c->ms.closed_form && c->d_shape && fa.xi != fa.xi_prev && c->graph.max_degree <= c8::GATHER_MAX_DEGREE &&
+         (c->kernel_variant == C8_KERNEL_AUTO || c->kernel_variant == C8_KERNEL_NODE);
+}
+static int node_rows_setup(c8_ctx* c) {
+  if (c->d_nr_order) return C8_OK;
+  c->nr_order.clear();
+  for (int32_t n = 0; n < c->mesh.nnodes; ++n)
+    if (c->graph.nodeelem_ptr[n + 1] > c->graph.nodeelem_ptr[n]) c->nr_order.push_back(n);
+  c->nr_early_count = 0;
+  if (c->early_end > c->early_begin) {  // the early nodes' rows first (stable: both parts keep ascending node order)
+    auto const early = [&](int32_t n) { return n >= c->early_begin && n < c->early_end; };
+    c->nr_early_count = (int)(std::stable_partition(c->nr_order.begin(), c->nr_order.end(), early) - c->nr_order.begin());
+  }
+  return upload(&c->d_nr_order, c->nr_order);
+}
+static int run_node_rows(c8_ctx* c, FieldArgs const& fa, SystemArgs const& sa) {
+  if (c->gather_pending) return fail(C8_ERR_ARG, "row-per-node assembly: c8_gather_finish has not been called for the previous assembly");
+  int rc = node_rows_setup(c);
+  if (rc) return rc;
+  GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, nullptr, 0, c->d_nr_order,
+                {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}, c->assign_mode};
+  MeshTables const mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params, c->d_shape};
+  int const total = (int)c->nr_order.size();
+  if (c->early_end > c->early_begin) {  // two parts: the early rows now, the rest in c8_gather_finish
+    C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, 0, c->nr_early_count, c->graph.max_degree, c->stream));
+    c->pending_ga = ga;
+    c->pending_fa = fa;
+    c->pending_node_rows = true;
+    c->gather_pending = true;
+    return C8_OK;  // the closed form has no failing local solve: nothing to read back
+  }
+  C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, 0, total, c->graph.max_degree, c->stream));
+  return C8_OK;
 }
 
 static MeshTables tables(c8_ctx const* c, bool colored);
@@ -423,6 +473,7 @@ static int run_staged(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs c
     C8_HIP(fn(a));
     C8_HIP(c->ks.gather_rows(ga, 0, c->early_count, c->graph.max_degree, c->stream));
     c->pending_ga = ga;
+    c->pending_node_rows = false;
     c->gather_pending = true;
     if (c->async) return C8_OK;
     return c8_status(c);
@@ -490,6 +541,9 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": staged (gather) assembly of hex8 adjoint Jacobians needs the wave-per-element kernel");
   if (c->assign_mode && scatters && sa.A[0][0] && !staged)
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": assign mode (c8_set_assign_mode) needs the staged Jacobian assembly (C8_SCATTER_GATHER)");
+  if (c->kernel_variant == C8_KERNEL_NODE && fn == c->ks.forward_jacobian_wave && !(staged && node_rows_applies(c, fa)))
+    return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": C8_KERNEL_NODE needs C8_SCATTER_GATHER, the shape-table cache and distinct xi / xi_prev arrays");
+  if (staged && fn == c->ks.forward_jacobian_wave && node_rows_applies(c, fa)) return run_node_rows(c, fa, sa);
   if (staged) {
     int const rc = run_staged(c, fn, fa, aa, sa);
     if (rc == C8_ERR_DEVICE && c->scatter_auto && !c->d_stage && !c->assign_mode && c->early_end <= c->early_begin) {

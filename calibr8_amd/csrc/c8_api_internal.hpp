@@ -53,6 +53,13 @@ struct c8_ctx {
   int early_begin = 0, early_end = 0, early_count = 0;
   bool gather_pending = false;
   c8::GatherArgs pending_ga{};
+  // row-per-node forward assembly (C8_KERNEL_NODE): its node order (nodes with elements, the early range first) and, for the
+  // two-part form, the fields the second part reads
+  std::vector<int32_t> nr_order;
+  int32_t* d_nr_order = nullptr;
+  int nr_early_count = 0;
+  bool pending_node_rows = false;
+  c8::FieldArgs pending_fa{};
   double* d_shape = nullptr;          // cached shape tables of the wave kernels, [nelems][ks.shape_stride] (hex8; null: computed per call)
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}
@@ -90,3 +97,4 @@ int c8_qoi_postprocess(c8_ctx* c, double* J);
 // c8_halo.hip: multi-part helpers for the other translation units
 int c8_parts_allreduce(c8_ctx* c, double* values, int n);  // SUM over the parts: caller's callback, else the halo's communicator; no-op on one part
 int c8_halo_num_owned(c8_halo const* h);
+void c8_halo_detach_ctx(c8_ctx* c);  // c8_destroy: the halo attached to c (if any) forgets the context and its communicator

@@ -210,7 +210,9 @@ int start_exchange(c8_halo* h, Exchange& x, Segs const& segs) {
   c8_ctx* c = h->ctx;
   c8_comm* cm = h->comm;
   if (h->pending) return c8_fail(C8_ERR_ARG, "halo: an exchange is already in flight");
-  if (x.nsend == 0 && x.nrecv == 0) return C8_OK;  // a part without neighbours
+  // a part without neighbours has nothing to move -- but the host transport's callback may be a collective over all
+  // ranks (torch.distributed all_to_all), so it is entered with all-zero counts; RCCL point-to-point needs no call
+  if (x.nsend == 0 && x.nrecv == 0 && cm->nccl) return C8_OK;
   if (x.nsend > 0) {
     hipLaunchKernelGGL(k_pack, dim3(grid_of(x.nsend)), dim3(TPB), 0, c->stream, x.nsend, x.d_send_idx, segs, h->d_sendbuf);
     C8H_HIP(hipGetLastError());
@@ -271,6 +273,16 @@ int c8_parts_allreduce(c8_ctx* c, double* values, int n) {
   return C8_OK;
 }
 int c8_halo_num_owned(c8_halo const* h) { return h->nowned; }
+void c8_halo_detach_ctx(c8_ctx* c) {
+  c8_halo* h = c->halo;
+  if (!h) return;
+  if (h->comm && h->comm->stream) (void)hipStreamSynchronize(h->comm->stream);
+  (void)hipStreamSynchronize(c->stream);
+  h->pending = nullptr;
+  h->ctx = nullptr;
+  h->comm = nullptr;
+  c->halo = nullptr;
+}
 
 extern "C" {
 
@@ -333,8 +345,9 @@ int c8_comm_size(const c8_comm* cm) { return cm ? cm->nranks : C8_ERR_ARG; }
 
 int c8_comm_allreduce_sum(c8_comm* cm, double* values, int n) {
   if (!cm || !values || n < 0) return c8_fail(C8_ERR_ARG, "c8_comm_allreduce_sum: bad argument");
-  if (n == 0 || cm->nranks == 1) return C8_OK;
+  if (n == 0) return C8_OK;
   if (!cm->nccl) {
+    if (cm->nranks == 1) return C8_OK;
     if (cm->host_allreduce(cm->user, values, n) != 0) return c8_fail(C8_ERR_ARG, "c8_comm_allreduce_sum: the host all-reduce callback failed");
     return C8_OK;
   }
@@ -531,6 +544,9 @@ int c8_halo_attach(c8_halo* h, c8_ctx* c, c8_comm* cm) {
 void c8_halo_destroy(c8_halo* h) {
   if (!h) return;
   if (h->ctx && h->ctx->halo == h) h->ctx->halo = nullptr;
+  // an exchange may still be in flight on the communicator's stream or waiting to be unpacked on the context's
+  if (h->comm && h->comm->stream) (void)hipStreamSynchronize(h->comm->stream);
+  if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
   for (Exchange* x : {&h->full, &h->bonly, &h->aonly, &h->import}) free_exchange(*x);
   (void)hipFree(h->d_sendbuf);
   (void)hipFree(h->d_recvbuf);

@@ -6,6 +6,7 @@
 
 #include "c8_assemble_adjoint.hpp"
 #include "c8_assemble_wave.hpp"
+#include "c8_assemble_node.hpp"
 #include "c8_kernels.hpp"
 
 namespace c8 {
@@ -415,6 +416,45 @@ template <class E> static hipError_t launch_gather_rows(GatherArgs const& ga, in
   return hipGetLastError();
 }
 
+// K1, one wavefront per node (c8_assemble_node.hpp): the node's rows formed from its elements with the model's closed form
+// and written once -- no element stage.  Contiguous eighths of the node order per XCD: neighbouring nodes share their
+// elements' shape tables and state in one L2.
+#ifndef C8_NODE_WAVES
+#define C8_NODE_WAVES 2
+#endif
+template <class E, template <class> class ModelT, int MAXDEG>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C8_NODE_WAVES, 4)))
+k_node_rows_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, GatherArgs ga, int first, int count, int nblocks) {
+  using Lane = NodeLane<MAXDEG>;
+  __shared__ NodeShared<E, ModelT<Dual>, MAXDEG> sh;
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks || lb >= count) return;
+  Lane L;
+  GpuExec<Lane> ex(threadIdx.x, L);
+  node_rows_closed<E, ModelT, MAXDEG>(ex, sh, mt, ms, fa, ga, ga.node_order[first + lb]);
+}
+template <class E, template <class> class ModelT>
+static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms, FieldArgs const& fa, GatherArgs const& ga,
+                                   int first, int count, int max_degree, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  int const nblocks = count;
+  int const grid = ((nblocks + 7) / 8) * 8;
+  if (max_degree <= 32)
+    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, 32>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
+  else if (max_degree <= GATHER_MAX_DEGREE)
+    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, GATHER_MAX_DEGREE>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT, class = void> struct NodeKernel {
+  static NodeRowsFn get() { return nullptr; }
+};
+template <template <class> class ModelT>
+struct NodeKernel<Elem<C8_HEX8>, ModelT, std::enable_if_t<has_closed_form_rows<ModelT<Dual>>::value>> {
+  static NodeRowsFn get() { return &launch_node_rows<Elem<C8_HEX8>, ModelT>; }
+};
+
 // group index -> element for the colour-batched / atomic element-parallel kernels
 #define C8_GROUP_PROLOGUE(E)                                                  \
   constexpr int GPB = BLOCK / E::NDOF;                                        \
@@ -601,6 +641,7 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.shape_tables = WK::shape_tables;
   ks.shape_stride = SHAPE_STRIDE;
   ks.gather_rows = &launch_gather_rows<E>;
+  ks.node_rows = NodeKernel<E, ModelT>::get();
   ks.stage_stride = stage_stride<E>();
   ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements
   ks.can_stage = E::DIM == 3;              // the stage and the row-sum kernel are laid out for 3 + 1 equations per node

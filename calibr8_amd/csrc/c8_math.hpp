@@ -39,6 +39,17 @@
 #define C8_STREAM_LOAD(p) (*(p))
 #define C8_STREAM_LOAD2(p, a, b) do { (a) = (p)[0]; (b) = (p)[1]; } while (0)
 #endif
+// the instruction scheduler does not move anything across this point (device builds; nothing on the host): keeps the
+// operands of one step of an unrolled loop from being fetched steps ahead, which costs registers
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define C8_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// ... and the value x is complete at this point of the instruction stream (an empty asm statement that takes and returns
+// it): together with the fence this keeps the arithmetic of one step of an unrolled loop between its two fences
+#define C8_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define C8_SCHED_FENCE() ((void)0)
+#define C8_PIN(x) ((void)0)
+#endif
 #if defined(__clang__)
 #define C8_UNROLL _Pragma("unroll")
 #define C8_NOUNROLL _Pragma("clang loop unroll(disable)")

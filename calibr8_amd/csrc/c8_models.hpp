@@ -316,6 +316,48 @@ template <class T, int DIM> struct SmallJ2Dim {
     double const tp = isp * tau;
     db[10] = -(tp * g[0]); db[11] = -(tp * g[1]); db[12] = -(tp * g[2]);
   }
+  // ---- the same tangent, one NODE PAIR at a time (the row-per-node kernel, c8_assemble_node.hpp) -----------------------------
+  // With g = dN_a/dx of the row node a and h = dN_m/dx of the column node m at a point, the 4 x 4 block
+  // d R_(a,.) / d x_(m,.) of the point follows from the columns above by contracting with the row node's shape entries:
+  //   (u_i, u_k)  w [ delta_ik a/2 (g.h) + a/2 g_k h_i - a/3 g_i h_k + b (n g)_i (n' h)_k ],   n' = n - tr(n)/3 I
+  //   (u_i, p)   -w g_i N_m        (p, u_k)  -w N_a h_k        (p, p)  -w N_a N_m / kappa - tau w (g.h)
+  // closed_form_row gathers what depends on the point and the ROW node only (NROW doubles), closed_form_block adds the block
+  // of one column node: 57 operations per point and node pair, no selects.
+  static constexpr bool HAS_CLOSED_FORM_ROWS = HAS_CLOSED_FORM;
+  static constexpr int NROW = 17;
+  // r: w g (3) | w b (n g) (3) | a/2 | -a/3 | n' (xx xy xz yy yz zz) | w N_a | w N_a / kappa | tau
+  C8_HD static void closed_form_row(double const* t, double w, double const* g, double Na, double* r) {
+    double const a = t[0], b = t[1], trn3 = t[2], inv_kappa = t[3], tau = t[4];
+    double const* n = t + 5;
+    r[0] = w * g[0]; r[1] = w * g[1]; r[2] = w * g[2];
+    double const wb = w * b;
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i) r[3 + i] = wb * (n[3 * i] * g[0] + n[3 * i + 1] * g[1] + n[3 * i + 2] * g[2]);
+    r[6] = 0.5 * a;
+    r[7] = -(a * (1. / 3.));
+    r[8] = n[0] - trn3; r[9] = n[1]; r[10] = n[2]; r[11] = n[4] - trn3; r[12] = n[5]; r[13] = n[8] - trn3;
+    double const wN = w * Na;
+    r[14] = wN; r[15] = wN * inv_kappa; r[16] = tau;
+  }
+  // J[4 i + k] += block entry (row i of the row node, column k of the column node; 3 = p)
+  C8_HD static void closed_form_block(double const* r, double const* h, double Nm, double* J) {
+    double const gh = r[0] * h[0] + r[1] * h[1] + r[2] * h[2];
+    double const nh[3] = {r[8] * h[0] + r[9] * h[1] + r[10] * h[2], r[9] * h[0] + r[11] * h[1] + r[12] * h[2],
+                          r[10] * h[0] + r[12] * h[1] + r[13] * h[2]};
+    double const p1[3] = {r[6] * r[0], r[6] * r[1], r[6] * r[2]};   // a/2 w g_k
+    double const p2[3] = {r[7] * h[0], r[7] * h[1], r[7] * h[2]};   // -a/3 h_k
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i)
+      C8_UNROLL
+      for (int k = 0; k < 3; ++k) J[4 * i + k] = fma(r[3 + i], nh[k], fma(r[i], p2[k], fma(p1[k], h[i], J[4 * i + k])));
+    double const d = r[6] * gh;
+    J[0] += d; J[5] += d; J[10] += d;
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i) J[4 * i + 3] = fma(-r[i], Nm, J[4 * i + 3]);
+    C8_UNROLL
+    for (int k = 0; k < 3; ++k) J[12 + k] = fma(-r[14], h[k], J[12 + k]);
+    J[15] = fma(-r[16], gh, fma(-r[15], Nm, J[15]));
+  }
 };
 template <class T> struct SmallJ2 : SmallJ2Dim<T, 3> {};       // "small_J2" on a 3-D mesh
 template <class T> struct SmallJ2Plane : SmallJ2Dim<T, 2> {};  // "small_J2" on a 2-D mesh (notch2D_small_J2.yaml.in)

@@ -316,7 +316,12 @@ int c8_primal_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, in
     c->async = 0;
     rc = S.agree(c8_assemble_forward_jacobian(c, st, sys));
     c->async = saved_async;
-    if (rc != C8_OK) return rc;
+    if (rc != C8_OK) {
+      // a failed assembly leaves A and b undefined (evaluations.cpp:95-97): the second part of two-part row sums
+      // (c8_set_gather_early_nodes) is dropped with it, so that the line search can contract and assemble again
+      c->gather_pending = c->pending_node_rows = false;
+      return rc;
+    }
     // tractions are added to the GHOST-distributed residual before the gather, as in the reference; in assign mode the
     // owned rows' sums would overwrite them, so those run first
     if (ntbc > 0 && c->assign_mode && (rc = c8_gather_finish(c)) != C8_OK) return rc;
@@ -410,6 +415,7 @@ int c8_adjoint_solve_step(c8_ctx* c, const c8_state* st, const c8_system* sys, i
   int const saved_async = c->async;
   c->async = 0;
   rc = S.agree(c8_assemble_adjoint_jacobian(c, st, g, f, sys));
+  if (rc != C8_OK) c->gather_pending = c->pending_node_rows = false;  // nothing is left waiting for c8_gather_finish after a failed assembly
   if (rc == C8_OK) rc = S.gather();  // gather_A / gather_b (adjoint.cpp:128-129)
   const double* zc[2] = {z[0], z[1]};
   if (rc == C8_OK) rc = c8_apply_dirichlet(c, ndbc, dbcs, zc, sys, 1);  // apply_primal_dbcs(..., is_adjoint) (adjoint.cpp:137)

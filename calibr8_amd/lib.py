@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libc8.so")
 C8_ELEM_TRI3, C8_ELEM_TET4, C8_ELEM_HEX8 = 3, 4, 8
 C8_OK, C8_LOCAL_SOLVE_FAILED, C8_ERR_ARG, C8_ERR_DEVICE, C8_ERR_UNSUPPORTED, C8_NOT_CONVERGED = 0, -1, -2, -3, -4, -5
 C8_SCATTER_ATOMIC, C8_SCATTER_COLORED, C8_SCATTER_GATHER = 0, 1, 2
-C8_KERNEL_AUTO, C8_KERNEL_SLOT, C8_KERNEL_WAVE, C8_KERNEL_WAVE_AD = 0, 1, 2, 3
+C8_KERNEL_AUTO, C8_KERNEL_SLOT, C8_KERNEL_WAVE, C8_KERNEL_WAVE_AD, C8_KERNEL_NODE = 0, 1, 2, 3, 4
 C8_SCALE_NONE, C8_SCALE_LOG, C8_SCALE_BOUNDS = 0, 1, 2
 
 dp = C.POINTER(C.c_double)

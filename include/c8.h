@@ -44,7 +44,7 @@ enum { C8_OK = 0, C8_LOCAL_SOLVE_FAILED = -1, C8_ERR_ARG = -2, C8_ERR_DEVICE = -
  * 64 neighbours.  If the stage cannot be allocated at the first Jacobian assembly, a context still in its default
  * mode switches to COLORED and says so in c8_last_error(). */
 enum { C8_SCATTER_ATOMIC = 0, C8_SCATTER_COLORED = 1, C8_SCATTER_GATHER = 2 };
-enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2, C8_KERNEL_WAVE_AD = 3 };
+enum { C8_KERNEL_AUTO = 0, C8_KERNEL_SLOT = 1, C8_KERNEL_WAVE = 2, C8_KERNEL_WAVE_AD = 3, C8_KERNEL_NODE = 4 };
 
 /* One mesh part (what Disc holds after loadMdsMesh, disc.cpp:31-39): all nodes that touch a
  * local element, local (GHOST) numbering. */
@@ -181,7 +181,14 @@ int c8_set_shape_cache(c8_ctx* ctx, int on);
  * Jacobian as the iterated form to within the local Newton tolerance (2e-13 measured).  C8_KERNEL_WAVE_AD (hex8) and an
  * explicit C8_KERNEL_SLOT keep the iterated, automatically differentiated form; it also runs whenever
  * local_max_iters < 8, so that a local solve that cannot converge within the caller's budget still reports
- * C8_LOCAL_SOLVE_FAILED as the reference does. */
+ * C8_LOCAL_SOLVE_FAILED as the reference does.
+ * C8_KERNEL_NODE (hex8, models with a closed form, C8_SCATTER_GATHER): eval_forward_jacobian with one wavefront per NODE --
+ * the wavefront forms the node's four CSR rows from the node's elements (closed form recomputed per node, every 4 x 4
+ * block of an element matrix formed once, by its row node) and writes them once: no element stage, no atomics, bitwise
+ * reproducible, a third of the staged form's memory traffic.  C8_KERNEL_AUTO takes it where it applies (cached shape
+ * tables present, st->xi and st->xi_prev distinct arrays); C8_KERNEL_WAVE keeps the staged one-wavefront-per-element form.
+ * It honours c8_set_assign_mode and c8_set_gather_early_nodes / c8_gather_finish like the staged form; between the
+ * assembly call and c8_gather_finish the arrays of `st` must stay as they were (the second part reads them). */
 int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 /* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
  * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */

@@ -14,6 +14,7 @@
 
 #include "../../calibr8_amd/csrc/c8_assemble_adjoint.hpp"
 #include "../../calibr8_amd/csrc/c8_assemble_wave.hpp"
+#include "../../calibr8_amd/csrc/c8_assemble_node.hpp"
 #include "../../calibr8_amd/csrc/c8_host.hpp"
 #include "../../calibr8_amd/csrc/c8_qoi_host.hpp"
 
@@ -75,7 +76,7 @@ template <class Lane, int NDOF> struct CpuExec {
   }
 };
 
-enum { K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 // objective configuration for the next calls (what c8_set_qoi_calibration / c8_set_measured keep in the context)
 struct EmuQoi {
@@ -234,6 +235,31 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
   delete shc;
 }
 
+// K1, one wavefront per node (c8_assemble_node.hpp): every node that has elements, in ascending order -- or, with
+// c.staged set, the upper half of the nodes first and the lower half afterwards, as the two-part form of the library does
+// (c8_set_gather_early_nodes + c8_gather_finish)
+template <template <class> class ModelT> static int run_node_rows(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  if constexpr (has_closed_form_rows<ModelT<Dual>>::value) {
+    if (!c.mt.shape || c.graph->max_degree > GATHER_MAX_DEGREE) return -4;
+    auto* sh = new NodeShared<E, ModelT<Dual>, GATHER_MAX_DEGREE>();
+    auto* ex = new CpuExec<NodeLane<GATHER_MAX_DEGREE>, 64>();
+    GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), nullptr, 0, nullptr,
+                  {{c.sa.A[0][0], c.sa.A[0][1]}, {c.sa.A[1][0], c.sa.A[1][1]}}, {c.sa.b[0], c.sa.b[1]}, c.assign};
+    auto one = [&](int n) {
+      if (c.graph->nodeelem_ptr[n + 1] > c.graph->nodeelem_ptr[n]) node_rows_closed<E, ModelT, GATHER_MAX_DEGREE>(*ex, *sh, c.mt, c.ms, c.fa, ga, n);
+    };
+    int const half = c.staged ? c.nnodes / 2 : 0;
+    for (int n = half; n < c.nnodes; ++n) one(n);
+    for (int n = 0; n < half; ++n) one(n);
+    delete ex;
+    delete sh;
+    return 0;
+  } else {
+    return -4;
+  }
+}
+
 template <template <class> class ModelT> static void run_residual_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new ResidualWaveShared<E>();
@@ -272,6 +298,11 @@ static int dispatch_2d(std::string const& model, Call const& c) {
 }
 
 template <class E> static int dispatch(std::string const& model, Call const& c) {
+  if (c.what == K_FORWARD_NODE) {
+    if (E::TYPE != C8_HEX8) return -4;
+    if (model == "small_J2") return run_node_rows<SmallJ2>(c);
+    return -4;
+  }
   if (c.what == K_QOI_WAVE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "elastic") run_qoi_wave<Elastic>(c);

@@ -16,7 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS = 11, 12, 13
+K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE = 11, 12, 13, 14
 
 
 def lib():
@@ -48,6 +48,7 @@ class Emul:
         self.wave = False  # True: K1 through the wave-per-element kernel (hex8 only)
         self.staged = False  # staged (gather) assembly of the two Jacobian kernels (hex8 slot K3 excepted)
         self.assign = False  # staged assembly: assign A and b instead of adding (c8_set_assign_mode)
+        self.node = False    # True: K1 through the row-per-node kernel (hex8 models with a closed form; staged = its two-part form)
         self.closed = True   # wave K1 of a model with a closed form (small_J2): that form, as the library's default; False: AD / Newton
         self.ls = (1e-4, 0.5, 0.9, 4)  # local line search (Hosford / Barlat models): defaults of line_search.hpp:28-35
 
@@ -95,7 +96,7 @@ class Emul:
         return {6: ls.A[0][0], 7: ls.A[0][1], 8: ls.A[1][0], 9: ls.A[1][1], 10: ls.b[0], 11: ls.b[1]}
 
     def forward_jacobian(self, u, p, up, pp, xip, xi, ls):
-        what = (K_FORWARD_WAVE if self.wave else K_FORWARD) | (256 if self.staged else 0) | (512 if self.assign else 0) | \
+        what = (K_FORWARD_NODE if self.node else K_FORWARD_WAVE if self.wave else K_FORWARD) | (256 if self.staged else 0) | (512 if self.assign else 0) | \
             (1024 if self.closed and self.max_iters >= 8 else 0)
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 

@@ -63,6 +63,50 @@ def test_forward_jacobian_wave_kernel_iterated_form(model, params, eps, staged):
     check_forward(orc, dut, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("two_part", [False, True])
+@pytest.mark.parametrize("model,params,eps", CASES[:2])
+def test_forward_jacobian_row_per_node_kernel(model, params, eps, two_part):
+    # one wavefront per NODE (c8_assemble_node.hpp): the node's four CSR rows formed from its elements with the model's
+    # closed form and written once, no element stage; two_part = half of the nodes first, the rest afterwards
+    # (c8_set_gather_early_nodes + c8_gather_finish)
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.node, dut.staged = True, two_part
+    check_forward(orc, dut, c, model, eps, TOL)
+
+
+def test_row_per_node_kernel_assign_mode_and_ragged_meshes():
+    import oracle_lib as ol
+    from meshes import brick, notched_bar, prescribed_fields
+    from parity import compare_systems, rel_vec
+    # assign mode on stale content = accumulate-into on zeros
+    orc, dut, c = make_pair(factory, "hex8", "small_J2", CASES[1][1])
+    dut.node = True
+    u, p = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    z, zp = np.zeros_like(u), np.zeros_like(p)
+    ls_o, ls_d, xo, xd = orc.new_linsys(), dut.new_linsys(), orc.new_state(), dut.new_state()
+    assert orc.forward_jacobian(u, p, z, zp, orc.new_state(), xo, ls_o) == 0
+    for i in range(2):
+        ls_d.b[i][:] = 7.0
+        for j in range(2):
+            ls_d.A[i][j][:] = -3.0
+    dut.assign = True
+    assert dut.forward_jacobian(u, p, z, zp, dut.new_state(), xd, ls_d) == 0
+    errs = compare_systems(orc, ls_d, ls_o)
+    errs["xi"] = rel_vec(xd, xo)
+    assert max(errs.values()) < TOL, errs
+    # accumulate-into: a second assembly doubles the system
+    dut.assign = False
+    assert dut.forward_jacobian(u, p, z, zp, dut.new_state(), xd, ls_d) == 0
+    assert np.abs(ls_d.A[0][0] - 2 * ls_o.A[0][0]).max() < 1e-12 * np.abs(ls_o.A[0][0]).max()
+    # one element, partial groups, and the notched bar (node degrees 8 .. 27, nodes with 1 .. 8 elements)
+    for mesh in (brick(1, 1, 1), brick(3, 1, 1, 3.0), brick(2, 3, 1, 2.0, 3.0), notched_bar(8, 6, 2)):
+        cc, conn = mesh[0], mesh[1]
+        orc = ol.Oracle(ol.HEX8, cc, conn, "small_J2", CASES[1][1])
+        dut = em.Emul(ol.HEX8, cc, conn, "small_J2", CASES[1][1])
+        dut.node = True
+        check_forward(orc, dut, cc, "small_J2", 0.0035, TOL)
+
+
 @pytest.mark.parametrize("params", [[1000.0, 0.25, 100.0, 2.0, 0.0, 0.0], [1000.0, 0.25, 0.0, 2.0, 0.0, 0.0],
                                     [1000.0, 0.25, 5000.0, 0.5, 0.0, 0.0]])
 def test_closed_form_against_iterated_form(params):

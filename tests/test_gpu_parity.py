@@ -228,6 +228,55 @@ def test_staged_gather_assign_mode():
         asm.forward_jacobian(u, p, z, zp, xi0, asm.new_state(), ls)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES[:2])
+def test_row_per_node_kernel_hex8(model, params, eps):
+    # C8_KERNEL_NODE: one wavefront per node forms the node's rows from its elements (closed form) and writes them once
+    orc, gpu, c = make_pair(factory("gather", "node"), "hex8", model, params)
+    check_forward(orc, gpu, c, model, eps, TOL)
+
+
+def test_row_per_node_kernel_ragged_meshes_sets_and_refusals():
+    import torch
+    from calibr8_amd import Assembler
+    from gpu_backend import GpuBackend
+    from meshes import notched_bar
+    for n in ((1, 1, 1), (3, 1, 1), (5, 1, 1), (3, 3, 1)):  # one element; nodes with one, two and four elements only
+        c, conn, _ = brick(n[0], n[1], n[2], 1.0 * n[0], 1.0 * n[1], 1.0 * n[2])
+        check_forward(ol.Oracle(ol.HEX8, c, conn, "small_J2", J2), GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather", kernel="node"),
+                      c, "small_J2", 0.0035, TOL)
+    check_two_element_sets(factory("gather", "node"), "hex8", TOL)
+    c, conn, _ = notched_bar(10, 6, 3)  # node degrees 8 .. 27, nodes with 1 .. 8 elements
+    orc, gpu = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2), GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather", kernel="node")
+    check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
+    # it is what the default takes for this model and element, bit for bit, and two runs agree bit for bit
+    c, conn = hex_mesh((5, 4, 3))
+    u_h, p_h = prescribed_fields(c, 0.004, ramp=True)
+    res = []
+    for kernel in ("auto", "node", "node", "wave"):
+        asm = Assembler(8, c, conn, "small_J2", J2, scatter="gather")
+        asm.set_kernel(kernel)
+        u, p = asm.dev(u_h), asm.dev(p_h)
+        ls, xi = asm.new_linsys(), asm.new_state()
+        assert asm.forward_jacobian(u, p, torch.zeros_like(u), torch.zeros_like(p), asm.new_state(), xi, ls) == 0
+        res.append((ls.flat.clone(), xi.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[1][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+    # the staged one-wavefront-per-element form computes the same system in another order
+    assert float((res[3][0] - res[0][0]).abs().max() / res[0][0].abs().max()) < 1e-13 and not torch.equal(res[3][0], res[0][0])
+    # where it does not apply: another scatter mode, previous and new state in one array, a model without a closed form
+    asm = Assembler(8, c, conn, "small_J2", J2, scatter="atomic")
+    asm.set_kernel("node")
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    with pytest.raises(RuntimeError, match="C8_KERNEL_NODE"):
+        asm.forward_jacobian(u, p, torch.zeros_like(u), torch.zeros_like(p), asm.new_state(), asm.new_state(), asm.new_linsys())
+    asm = Assembler(8, c, conn, "small_J2", J2, scatter="gather")
+    xi = asm.new_state()
+    ls = asm.new_linsys()
+    assert asm.forward_jacobian(u, p, torch.zeros_like(u), torch.zeros_like(p), xi, xi, ls) == 0  # default: the staged form takes over
+    assert float((ls.flat - res[0][0]).abs().max() / res[0][0].abs().max()) < 1e-13
+    with pytest.raises(RuntimeError, match="closed form"):
+        Assembler(8, c, conn, "hyper_J2", HJ2).set_kernel("node")
+
+
 def test_staged_gather_slot_kernel_hex8():
     orc, gpu, c = make_pair(factory("gather", "slot"), "hex8", "small_J2", J2)
     check_forward(orc, gpu, c, "small_J2", 0.004, TOL)

@@ -162,6 +162,42 @@ def test_device_newton_driver_matches_oracle_driven_newton():
     assert abs(pr.qoi() - ref.qoi()) < 1e-12
 
 
+def test_line_search_contracts_over_failed_trials_with_two_part_row_sums():
+    # a trial step whose local solves fail makes the search contract (primal.cpp:165, line_search.hpp:103-107).  With the
+    # row sums in two parts (c8_set_gather_early_nodes, the mode of multi-part meshes) the failed assembly used to leave
+    # its second part pending, and the next trial was refused: the step must run as in single-part mode.
+    from calibr8_amd import Assembler, PrimalDriver
+    c, conn, sets = brick(3, 3, 4, 1.0, 1.0, 1.5)
+    zero = lambda x, y, z, t: 0.0
+    spec = [(0, 0, sets["xmin"], zero), (0, 1, sets["ymin"], zero), (0, 2, sets["zmin"], zero),
+            (0, 2, sets["zmax"], lambda x, y, z, t: 0.12 * t)]
+    hill = [1000.0, 0.25, 2.0, 1.0, 1.1, 0.9, 1.05, 0.95, 1.0, 1.0, 50.0]
+    # eight local Newton iterations: enough at the converged steps, too few at the first full Newton steps of this load
+    orc = ol.Oracle(ol.HEX8, c, conn, "small_hill", hill, max_iters=8)
+    failed = [0]
+    plain = orc.forward_jacobian
+
+    def counted(*a, **k):
+        rc = plain(*a, **k)
+        failed[0] += rc != 0
+        return rc
+
+    orc.forward_jacobian = counted
+    ref = Primal(orc, c, [Dbc(*s) for s in spec], max_iters=25, abs_tol=1e-10, rel_tol=1e-10).solve(2)
+    assert failed[0] > 0  # the case does exercise failed trials
+    runs = []
+    for early in (None, (5, 30)):
+        asm = Assembler(8, c, conn, "small_hill", hill, max_iters=8)
+        if early:
+            asm.set_gather_early_nodes(*early)
+        runs.append(PrimalDriver(asm, spec, max_iters=25, abs_tol=1e-10, rel_tol=1e-10).solve(2))
+    one, two = runs
+    assert one.newton_iters == two.newton_iters == ref.newton_iters
+    for s in (1, 2):
+        assert np.array_equal(one.u[s].cpu().numpy(), two.u[s].cpu().numpy())  # the two-part row sums are bitwise the same
+        assert np.abs(one.u[s].cpu().numpy() - ref.u[s]).max() < 1e-9 * np.abs(ref.u[s]).max()
+
+
 def test_device_adjoint_driver_gradient():
     # c8_adjoint_solve_step marched backwards = the oracle-driven adjoint (fe_driver.adjoint_gradient),
     # and the reference's finite-difference gradient check with everything on the device
