@@ -335,8 +335,8 @@ int c8_gather_finish(c8_ctx* c) {
   if (c->pending_node_rows) {
     c->pending_node_rows = false;
     MeshTables const mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params, c->d_shape};
-    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, c->pending_ga, c->nr_early_count, (int)c->nr_order.size() - c->nr_early_count,
-                           c->graph.max_degree, c->stream));
+    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, c->pending_ga, 0, c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, c->pending_ga, c->early_end, c->mesh.nnodes - c->early_end, c->graph.max_degree, c->graph.max_node_elems, c->stream));
     return C8_OK;
   }
   int const total = (int)c->plan.node_order.size();
@@ -413,10 +413,8 @@ static int stage_setup(c8_ctx* c) {
 static void stage_release(c8_ctx* c) {
   (void)hipFree(c->d_stage);
   (void)hipFree(c->d_node_order);
-  (void)hipFree(c->d_nr_order);
   c->d_stage = nullptr;
   c->d_node_order = nullptr;
-  c->d_nr_order = nullptr;
 }
 
 // Row-per-node forward assembly (c8_assemble_node.hpp): whether this call takes it, and its launches.
@@ -424,35 +422,26 @@ static bool node_rows_applies(c8_ctx const* c, FieldArgs const& fa) {
   return c->ks.node_rows && c->ms.closed_form && c->d_shape && fa.xi != fa.xi_prev && c->graph.max_degree <= c8::GATHER_MAX_DEGREE &&
          (c->kernel_variant == C8_KERNEL_AUTO || c->kernel_variant == C8_KERNEL_NODE);
 }
-static int node_rows_setup(c8_ctx* c) {
-  if (c->d_nr_order) return C8_OK;
-  c->nr_order.clear();
-  for (int32_t n = 0; n < c->mesh.nnodes; ++n)
-    if (c->graph.nodeelem_ptr[n + 1] > c->graph.nodeelem_ptr[n]) c->nr_order.push_back(n);
-  c->nr_early_count = 0;
-  if (c->early_end > c->early_begin) {  // the early nodes' rows first (stable: both parts keep ascending node order)
-    auto const early = [&](int32_t n) { return n >= c->early_begin && n < c->early_end; };
-    c->nr_early_count = (int)(std::stable_partition(c->nr_order.begin(), c->nr_order.end(), early) - c->nr_order.begin());
-  }
-  return upload(&c->d_nr_order, c->nr_order);
-}
+// nodes [0, nnodes) in one launch; with an early node range set, that range now and the two ranges around it in
+// c8_gather_finish (the kernel takes a contiguous range of node numbers: no order table between the launch and the node)
 static int run_node_rows(c8_ctx* c, FieldArgs const& fa, SystemArgs const& sa) {
   if (c->gather_pending) return fail(C8_ERR_ARG, "row-per-node assembly: c8_gather_finish has not been called for the previous assembly");
-  int rc = node_rows_setup(c);
-  if (rc) return rc;
-  GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, nullptr, 0, c->d_nr_order,
+  GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, nullptr, 0, nullptr,
                 {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}, c->assign_mode};
   MeshTables const mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params, c->d_shape};
-  int const total = (int)c->nr_order.size();
+#ifdef C8_STAMPS
+  if (!c->d_stamps) C8_HIP(hipMalloc((void**)&c->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
+  ga.stamps = c->d_stamps;
+#endif
   if (c->early_end > c->early_begin) {  // two parts: the early rows now, the rest in c8_gather_finish
-    C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, 0, c->nr_early_count, c->graph.max_degree, c->stream));
+    C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, c->early_begin, c->early_end - c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
     c->pending_ga = ga;
     c->pending_fa = fa;
     c->pending_node_rows = true;
     c->gather_pending = true;
     return C8_OK;  // the closed form has no failing local solve: nothing to read back
   }
-  C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, 0, total, c->graph.max_degree, c->stream));
+  C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, 0, c->mesh.nnodes, c->graph.max_degree, c->graph.max_node_elems, c->stream));
   return C8_OK;
 }
 

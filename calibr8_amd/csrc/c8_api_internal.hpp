@@ -53,11 +53,7 @@ struct c8_ctx {
   int early_begin = 0, early_end = 0, early_count = 0;
   bool gather_pending = false;
   c8::GatherArgs pending_ga{};
-  // row-per-node forward assembly (C8_KERNEL_NODE): its node order (nodes with elements, the early range first) and, for the
-  // two-part form, the fields the second part reads
-  std::vector<int32_t> nr_order;
-  int32_t* d_nr_order = nullptr;
-  int nr_early_count = 0;
+  // row-per-node forward assembly (C8_KERNEL_NODE) in two parts: the fields the second part reads
   bool pending_node_rows = false;
   c8::FieldArgs pending_fa{};
   double* d_shape = nullptr;          // cached shape tables of the wave kernels, [nelems][ks.shape_stride] (hex8; null: computed per call)

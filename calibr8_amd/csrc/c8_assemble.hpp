@@ -102,6 +102,9 @@ struct GatherArgs {
   double* A[2][2];
   double* b[2];
   int assign = 0;               // 1: the rows are assigned (A = sum, b = sum) instead of added to (c8_set_assign_mode)
+#ifdef C8_STAMPS
+  unsigned long long* stamps = nullptr;  // diagnostic build only: [4096][16] s_memtime stamps of sampled nodes (row-per-node kernel)
+#endif
 };
 // stage[e]: for every element node n the four rows (u_0, u_1, u_2, p) of that node, NDOF columns each, in element
 // DOF order -- the 4*NDOF values a node's row sum needs from this element are contiguous -- then the NDOF entries of

@@ -5,7 +5,7 @@
 // shape -- element matrices go to an element-major stage (8.4 KB per hex8 element), a second kernel sums the rows of
 // each node -- and move six times the bytes the assembly needs.  Here the loop is turned inside out: a wavefront OWNS
 // the four CSR rows (u_0, u_1, u_2, p) of one node, forms them from the node's (up to eight) elements and writes each
-// row once.  No stage, no atomics, every sum in a fixed order: bitwise reproducible.
+// row once.  No stage, no atomics on global memory, every sum in a fixed order: bitwise reproducible.
 //
 // What makes it affordable is the model's closed form (Model::closed_form, Model::closed_form_row / _block): the
 // tangent data of a point are a handful of doubles, so the eight nodes of an element each recompute them (on all 64
@@ -29,64 +29,121 @@
 
 #include "c8_assemble_wave.hpp"
 
+// Diagnostic build only (-DC8_STAMPS, tools/stamp_node.py): s_memtime stamps at the phase boundaries of sampled nodes.
+#ifdef C8_STAMPS
+#define C8_NSTAMP(i) ex.stamp_node(ga.stamps, node, i)
+#else
+#define C8_NSTAMP(i)
+#endif
+
 namespace c8 {
 
 template <class M, class = void> struct has_closed_form_rows : std::false_type {};
 template <class M> struct has_closed_form_rows<M, std::enable_if_t<M::HAS_CLOSED_FORM_ROWS>> : std::true_type {};
 
-template <class E, class ModelD, int MAXDEG> struct NodeShared {
+// MANY = false (every node of the mesh has at most eight elements): the row accumulator takes the place of the point
+// records once phase B has read them; MANY = true: a node's elements go through phases A-C eight at a time and the
+// accumulator has its own storage.
+template <class E, class ModelD, int MAXDEG, bool MANY> struct NodeShared {
   static constexpr int NR = ModelD::NROW;
-  static constexpr int LDR = (NR + 4) | 1;  // record + the point's four residual contributions; odd stride
-  static constexpr int LDA = 17;            // one double of padding per accumulator row (see GatherShared)
-  double rec[8][E::NP0][LDR];
-  double acc[MAXDEG][LDA];
-  double Ntab[E::NP0][E::NN];               // shape values of the reference element at the points
+  // record + the point's four residual shares.  Even (16-byte LDS reads) and such that the records of two elements lie
+  // 32 banks apart modulo the 64 banks (8 points * LDR * 8 bytes = 128 modulo 256): the two element groups of a
+  // 16-lane LDS access then never meet in a bank
+  static constexpr int LDR = NR + 4;
+  static_assert(LDR % 2 == 0 && (E::NP0 * LDR * 8) % 256 == 128, "record stride: 16-byte aligned, element groups 32 banks apart");
+  static constexpr int LDA = 18;            // accumulator row: 16 entries + padding, 16-byte aligned
+  static constexpr int NREC = 8 * E::NP0 * LDR, NACC = MAXDEG * LDA;
+  alignas(16) double buf[MANY ? NREC + NACC : (NREC > NACC ? NREC : NACC)];
+  alignas(16) double nodal[8][E::NN][4];    // (u_0, u_1, u_2, p) of the nodes of the eight elements, loaded one node per lane
+  double el[8][2];                          // per element: the model's per-element scalars (closed_form_row)
   double bsum[4];
+  C8_HD double* rec(int s, int pt) { return buf + (s * E::NP0 + pt) * LDR; }
+  C8_HD double* acc(int pos) { return buf + (MANY ? NREC : 0) + pos * LDA; }
 };
+
+// nodes of the point's shape table that phase A fetches together with the nodal values, one memory round trip before their
+// use (0 .. 8; tuning switch, same results).  Every prefetched node costs six registers over the phase: with none the kernel
+// runs three waves per SIMD, with all eight two.
+#ifndef C8_TUNE_NODE_PREFETCH
+#define C8_TUNE_NODE_PREFETCH 0
+#endif
+constexpr int NODE_PFN = C8_TUNE_NODE_PREFETCH;
 
 template <int MAXDEG> struct NodeLane {
   static constexpr int N00 = (9 * MAXDEG + 63) / 64, N01 = (3 * MAXDEG + 63) / 64;
   double J[16];
   double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
+  double bold;                               // ... and of its residual entry (lanes 0..3)
   double rs;
+  // phase A: operands of this lane's point, fetched with the nodal values (one memory round trip earlier than their use)
+  double dn[NODE_PFN > 0 ? NODE_PFN : 1][3], xo[8], wdv;
   int e, a, pos;
   bool valid;
 };
 
-template <class E, template <class> class ModelT, int MAXDEG, class EX>
-C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG>& sh, MeshTables const& mt, ModelSettings const& ms,
+// shape values of the reference hex8 at its Gauss points: E::N(n, xi) operation for operation, 0.125 (1 + sx xi_0)
+// (1 + sy xi_1) (1 + sz xi_2), with either the point (of_point) or the node (of_node) fixed per lane and the other index a
+// compile-time constant or a lane value; signs are selected as values (no indexed tables: they would live in scratch)
+template <class E> struct HexShape {
+  double c[3];  // of_point: the point's coordinates; of_node: the node's signs
+  C8_HD static HexShape of_point(int pt) {
+    double w;
+    HexShape h;
+    E::point(0, pt, h.c, w);
+    return h;
+  }
+  C8_HD double at_node(int n) const {
+    double const sx = ((n ^ (n >> 1)) & 1) ? 1. : -1., sy = ((n >> 1) & 1) ? 1. : -1., sz = ((n >> 2) & 1) ? 1. : -1.;  // E::sign
+    return 0.125 * (1. + sx * c[0]) * (1. + sy * c[1]) * (1. + sz * c[2]);
+  }
+  C8_HD static HexShape of_node(int n) {
+    HexShape h;
+    E::sign(n, h.c[0], h.c[1], h.c[2]);
+    return h;
+  }
+  C8_HD double at_point(int pt) const {
+    double xi[3], w;
+    E::point(0, pt, xi, w);
+    return 0.125 * (1. + c[0] * xi[0]) * (1. + c[1] * xi[1]) * (1. + c[2] * xi[2]);
+  }
+};
+
+template <class E, template <class> class ModelT, int MAXDEG, bool MANY, class EX>
+C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& sh, MeshTables const& mt, ModelSettings const& ms,
                             FieldArgs const& fa, GatherArgs const& ga, int node) {
   using Model = ModelT<Dual>;
-  using SH = NodeShared<E, Model, MAXDEG>;
+  using SH = NodeShared<E, Model, MAXDEG, MANY>;
   using NL_ = NodeLane<MAXDEG>;
   constexpr int NL = Model::NLOC, NR = SH::NR;
   static_assert(E::NN == 8 && E::NP0 == 8 && E::SAME_POINTS, "row-per-node kernel: hex8-like element");
   static_assert(!Mechanics::USES_U && !Model::FINITE_DEF, "row-per-node kernel: small-strain weak form without u terms");
+  C8_NSTAMP(6);
   int const nptr = ga.nodeptr[node], deg = ga.nodeptr[node + 1] - nptr;
   int const e0 = ga.nodeelem_ptr[node], e1 = ga.nodeelem_ptr[node + 1];
   size_t const np = (size_t)nptr;
   int const n3 = 3 * deg;
-  ex.each([&](int lane) {
-    auto& r = ex.lane(lane);
+  if (e0 == e1) return;  // a node without elements (phantom columns of a mesh part): its rows are not touched
+  C8_NSTAMP(0);
+  auto zero_acc = [&](int lane) {
     C8_UNROLL
     for (int it = 0; it < (MAXDEG * SH::LDA + 63) / 64; ++it) {
       int const q = lane + 64 * it;
-      if (q < deg * SH::LDA) (&sh.acc[0][0])[q] = 0.;
-    }
-    {
-      double xi[3], w;
-      E::point(0, lane >> 3, xi, w);
-      sh.Ntab[lane >> 3][lane & 7] = E::N(lane & 7, xi);
+      if (q < deg * SH::LDA) sh.acc(0)[q] = 0.;
     }
     if (lane < 4) sh.bsum[lane] = 0.;
-  });
-  ex.sync();
-  for (int c0 = e0; c0 < e1; c0 += 8) {  // eight elements of the node at a time (a node of a hex8 mesh rarely has more)
+  };
+  if (MANY) {
+    ex.each([&](int lane) { zero_acc(lane); });
+    ex.sync();
+  }
+  for (int c0 = e0; c0 < e1; c0 += 8) {  // eight elements of the node at a time (MANY = false: exactly one round)
     int const ne = (e1 - c0 < 8) ? e1 - c0 : 8;
-    // ---- phase A: lane = (element s, point) ------------------------------------------------------------------------
+    // ---- phase A: nodal values, lane = (element s, node m): every lane fetches one node of one element, the eight lanes
+    //      of an element then read all eight from LDS (a lane per point fetching its own copies costs eight times the
+    //      loads and their registers) ------------------------------------------------------------------------------------
     ex.each([&](int lane) {
       auto& r = ex.lane(lane);
-      int const s = lane >> 3, pt = lane & 7;
+      int const s = lane >> 3, m = lane & 7;
       r.valid = s < ne;
       r.rs = 0.;
       if (!r.valid) return;
@@ -94,30 +151,68 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG>& sh, Mes
       int const e = packed >> 3, a = packed & 7;
       r.e = e;
       r.a = a;
+      // phase B's operand of this lane (column node m): position of m in the node's graph row
+      r.pos = ga.pos[((size_t)e * E::NN + m) * E::NN + a];
+      int const nd = mt.conn[(size_t)e * E::NN + m];
+      {  // this lane's point in the second half of the phase: pt = m
+        double const* const t = mt.shape + (size_t)e * SHAPE_STRIDE;
+        C8_UNROLL
+        for (int k = 0; k < NODE_PFN; ++k) {
+          r.dn[k][0] = t[(m * E::NN + k) * 3 + 0];
+          r.dn[k][1] = t[(m * E::NN + k) * 3 + 1];
+          r.dn[k][2] = t[(m * E::NN + k) * 3 + 2];
+        }
+        if (NODE_PFN > 0) {
+          r.wdv = t[SHAPE_WDV + m];
+          size_t const q0 = ((size_t)e * E::NP0 + m) * NL;
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) r.xo[j] = fa.xi_prev[q0 + j];
+        }
+      }
+      double* const nv = sh.nodal[s][m];
+      nv[0] = fa.u[(size_t)nd * 3 + 0]; nv[1] = fa.u[(size_t)nd * 3 + 1]; nv[2] = fa.u[(size_t)nd * 3 + 2];
+      nv[3] = fa.p[nd];
+    });
+    ex.sync();
+    // ---- phase A, continued: lane = (element s, point) ---------------------------------------------------------------
+    ex.each([&](int lane_) {
+      auto& r = ex.lane(lane_);
+      int lane = lane_;
+      C8_PIN(lane);  // the shape values below are formed here, not at the top of the kernel and kept in registers
+      int const s = lane >> 3, pt = lane & 7;
+      if (!r.valid) return;
+      int const e = r.e, a = r.a;
       double const* const t = mt.shape + (size_t)e * SHAPE_STRIDE;
-      int32_t const* const cn = mt.conn + (size_t)e * E::NN;
-      // phase B's operand of this lane (column node m = lane & 7): position of m in the node's graph row
-      r.pos = ga.pos[((size_t)e * E::NN + pt) * E::NN + a];
-      // interpolation (global_residual.cpp:289-332): the same sequential sums over the nodes as interp_ab
+      HexShape<E> const Np = HexShape<E>::of_point(pt);
+      // interpolation (global_residual.cpp:289-332): the same sequential sums over the nodes as interp_ab; four nodes'
+      // operands in flight at a time
       double q[WQ];
       C8_UNROLL
       for (int c = 0; c < WQ; ++c) q[c] = 0.;
       C8_UNROLL
       for (int m = 0; m < E::NN; ++m) {
-        int const nd = cn[m];
-        double const d0 = t[(pt * E::NN + m) * 3 + 0], d1 = t[(pt * E::NN + m) * 3 + 1], d2 = t[(pt * E::NN + m) * 3 + 2];
-        double const Nm = sh.Ntab[pt][m];
-        double const u0 = fa.u[(size_t)nd * 3 + 0], u1 = fa.u[(size_t)nd * 3 + 1], u2 = fa.u[(size_t)nd * 3 + 2], pm = fa.p[nd];
+        bool const pf = m < NODE_PFN;
+        double const d0 = pf ? r.dn[pf ? m : 0][0] : t[(pt * E::NN + m) * 3 + 0], d1 = pf ? r.dn[pf ? m : 0][1] : t[(pt * E::NN + m) * 3 + 1],
+                     d2 = pf ? r.dn[pf ? m : 0][2] : t[(pt * E::NN + m) * 3 + 2];
+        double const Nm = Np.at_node(m);
+        double const* const nv = sh.nodal[s][m];
+        double const u0 = nv[0], u1 = nv[1], u2 = nv[2], pm = nv[3];
         q[0] += u0 * d0; q[1] += u0 * d1; q[2] += u0 * d2;
         q[3] += u1 * d0; q[4] += u1 * d1; q[5] += u1 * d2;
         q[6] += u2 * d0; q[7] += u2 * d1; q[8] += u2 * d2;
         q[9] += pm * Nm;
         q[10] += pm * d0; q[11] += pm * d1; q[12] += pm * d2;
+        if (m == 3 || m == 7) {
+          C8_UNROLL
+          for (int c = 0; c < 13; ++c) C8_PIN(q[c]);
+          C8_SCHED_FENCE();
+        }
       }
+      C8_NSTAMP(7);
       size_t const q0 = ((size_t)e * E::NP0 + pt) * NL;
       double xi_old[NL];
       C8_UNROLL
-      for (int j = 0; j < NL; ++j) xi_old[j] = fa.xi_prev[q0 + j];
+      for (int j = 0; j < NL; ++j) xi_old[j] = NODE_PFN > 0 ? r.xo[j] : fa.xi_prev[q0 + j];
       int const es = mt.elem_set ? mt.elem_set[e] : 0;
       typename Model::ClosedForm cf;
       Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, q, xi_old, ms.abs_tol, t[SHAPE_H], ms.stab_mult, cf, true);
@@ -125,85 +220,127 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG>& sh, Mes
         C8_UNROLL
         for (int j = 0; j < NL; ++j) fa.xi[q0 + j] = cf.xi[j];
       }
-      double const w = t[SHAPE_WDV + pt];
+      C8_NSTAMP(8);
+      double const w = NODE_PFN > 0 ? r.wdv : t[SHAPE_WDV + pt];
       double const g[3] = {t[(pt * E::NN + a) * 3 + 0], t[(pt * E::NN + a) * 3 + 1], t[(pt * E::NN + a) * 3 + 2]};
-      double const Na = sh.Ntab[pt][a];
-      double* const rc = sh.rec[s][pt];
-      Model::closed_form_row(cf.t, w, g, Na, rc);
+      double const Na = Np.at_node(a);
+      double* const rc = sh.rec(s, pt);
+      double el[2];
+      Model::closed_form_row(cf.t, w, g, Na, rc, el);
+      if (pt == 0) { sh.el[s][0] = el[0]; sh.el[s][1] = el[1]; }
       // the point's share of R_(node,.): fluxes contracted with the row node's shape entries
       C8_UNROLL
       for (int i = 0; i < 3; ++i) rc[NR + i] = w * (cf.F[3 * i] * g[0] + cf.F[3 * i + 1] * g[1] + cf.F[3 * i + 2] * g[2]);
       rc[NR + 3] = w * (cf.F[9] * Na + cf.F[10] * g[0] + cf.F[11] * g[1] + cf.F[12] * g[2]);
     });
     ex.sync();
+    C8_NSTAMP(1);
     // ---- phase B: lane = (element s, column node m) ----------------------------------------------------------------
-    ex.each([&](int lane) {
-      auto& r = ex.lane(lane);
+    ex.each([&](int lane_) {
+      auto& r = ex.lane(lane_);
+      int lane = lane_;
+      C8_PIN(lane);
       C8_UNROLL
       for (int j = 0; j < 16; ++j) r.J[j] = 0.;
       if (!r.valid) return;
       int const s = lane >> 3, m = lane & 7;
       double const* const t = mt.shape + (size_t)r.e * SHAPE_STRIDE;
-      double h[E::NP0][3];  // dN_m/dx of this lane's column node at the eight points (the element's table is in L1 / L2 by now)
-      C8_UNROLL
-      for (int q = 0; q < E::NP0; ++q) {
-        h[q][0] = t[(q * E::NN + m) * 3 + 0];
-        h[q][1] = t[(q * E::NN + m) * 3 + 1];
-        h[q][2] = t[(q * E::NN + m) * 3 + 2];
-      }
+      HexShape<E> const Nn = HexShape<E>::of_node(m);
+      double const el[2] = {sh.el[s][0], sh.el[s][1]};
+      // dN_m/dx of this lane's column node, one point ahead of the arithmetic (the element's table is in L1 / L2 by now)
+      double hc[3] = {t[m * 3 + 0], t[m * 3 + 1], t[m * 3 + 2]};
       C8_UNROLL
       for (int pt = 0; pt < E::NP0; ++pt) {
-        Model::closed_form_block(sh.rec[s][pt], h[pt], sh.Ntab[pt][m], r.J);
-        // one point's record in registers at a time: without the two lines below the compiler fetches the records of all
-        // eight points first (136 doubles) and spills
+        double hn[3] = {0., 0., 0.};
+        if (pt + 1 < E::NP0) {
+          hn[0] = t[((pt + 1) * E::NN + m) * 3 + 0];
+          hn[1] = t[((pt + 1) * E::NN + m) * 3 + 1];
+          hn[2] = t[((pt + 1) * E::NN + m) * 3 + 2];
+        }
+        Model::closed_form_block(sh.rec(s, pt), el, hc, Nn.at_point(pt), r.J);
+        // one point's record in registers at a time: without the lines below the compiler fetches the records of all
+        // eight points first (over a hundred doubles) and spills
         C8_UNROLL
         for (int j = 0; j < 16; ++j) C8_PIN(r.J[j]);
         C8_SCHED_FENCE();
+        hc[0] = hn[0]; hc[1] = hn[1]; hc[2] = hn[2];
       }
       if (m < 4) {
         double v = 0.;
         C8_UNROLL
-        for (int pt = 0; pt < E::NP0; ++pt) v += sh.rec[s][pt][NR + m];
+        for (int pt = 0; pt < E::NP0; ++pt) v += sh.rec(s, pt)[NR + m];
         r.rs = v;
       }
     });
-    // ---- phase C: the elements' blocks into the row accumulator, one element after the other ------------------------
+    C8_NSTAMP(2);
+    if (c0 == e0) {
+      // the CSR entries this lane updates in phase D, fetched while phase C runs (assign mode: nothing to read, the rows start from
+      // zero -- uniform over the launch).  Not earlier: the counter of outstanding loads is in order, so the first wait of
+      // phase B for a shape entry out of L2 would also wait for these, which come from HBM
+      ex.each([&](int lane_) {
+        auto& r = ex.lane(lane_);
+        int lane = lane_;
+        C8_PIN(lane);  // what follows is derived from the lane number here, not at the top of the kernel and kept in registers
+        C8_UNROLL
+        for (int it = 0; it < NL_::N00; ++it) {
+          int const j = lane + 64 * it;
+          r.a00[it] = 0.;
+          if (!ga.assign && j < 9 * deg) r.a00[it] = ga.A[0][0][np * 9 + j];
+        }
+        C8_UNROLL
+        for (int it = 0; it < NL_::N01; ++it) {
+          int const j = lane + 64 * it;
+          r.a01[it] = r.a10[it] = 0.;
+          if (!ga.assign && j < n3) { r.a01[it] = ga.A[0][1][np * 3 + j]; r.a10[it] = ga.A[1][0][np * 3 + j]; }
+        }
+        r.a11 = 0.;
+        if (!ga.assign && lane < deg) r.a11 = ga.A[1][1][np + lane];
+        r.bold = 0.;
+        if (!ga.assign && lane < 4) r.bold = lane < 3 ? ga.b[0][(size_t)node * 3 + lane] : ga.b[1][node];
+      });
+    }
+    if (!MANY) {  // the accumulator takes the records' place
+      ex.sync();
+      ex.each([&](int lane) { zero_acc(lane); });
+    }
+    ex.sync();
+    C8_NSTAMP(3);
+    // ---- phase C: the elements' blocks into the row accumulator, one element after the other.  LDS operations of a
+    //      wavefront execute in order, so the sums into one entry are taken in ascending element order; within one
+    //      element the column nodes are distinct and so are the addresses ------------------------------------------
     for (int s2 = 0; s2 < ne; ++s2) {
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
         if ((lane >> 3) != s2) return;
-        double* const ac = sh.acc[r.pos];
+        double* const ac = sh.acc(r.pos);
         C8_UNROLL
-        for (int j = 0; j < 16; ++j) ac[j] += r.J[j];   // distinct column nodes: distinct addresses within the instruction
-        if ((lane & 7) < 4) sh.bsum[lane & 7] += r.rs;
+        for (int j = 0; j < 16; ++j) ex.lds_add(ac + j, r.J[j]);
+        if ((lane & 7) < 4) ex.lds_add(&sh.bsum[lane & 7], r.rs);
       });
-      ex.sync();
     }
+    ex.sync();
+    C8_NSTAMP(4);
   }
   // ---- phase D: rows out (the tail of gather_node_rows) -------------------------------------------------------------
-  ex.each([&](int lane) {
-    auto& r = ex.lane(lane);
-    // the CSR entries this lane updates (assign mode: nothing to read, the rows start from zero -- uniform over the launch)
+  ex.each([&](int lane_) {
+    auto& r = ex.lane(lane_);
+    int lane = lane_;
+    C8_PIN(lane);
+    // all fetched values complete HERE, once, outside the conditional stores below: with the waits inside the branches the
+    // compiler's count of outstanding memory operations is lost at every join, and it then drains the counter -- the
+    // previous store included -- in front of each store (ten serialised write round trips per node)
     C8_UNROLL
-    for (int it = 0; it < NL_::N00; ++it) {
-      int const j = lane + 64 * it;
-      r.a00[it] = 0.;
-      if (!ga.assign && j < 9 * deg) r.a00[it] = ga.A[0][0][np * 9 + j];
-    }
+    for (int it = 0; it < NL_::N00; ++it) C8_PIN(r.a00[it]);
     C8_UNROLL
-    for (int it = 0; it < NL_::N01; ++it) {
-      int const j = lane + 64 * it;
-      r.a01[it] = r.a10[it] = 0.;
-      if (!ga.assign && j < n3) { r.a01[it] = ga.A[0][1][np * 3 + j]; r.a10[it] = ga.A[1][0][np * 3 + j]; }
-    }
-    r.a11 = 0.;
-    if (!ga.assign && lane < deg) r.a11 = ga.A[1][1][np + lane];
+    for (int it = 0; it < NL_::N01; ++it) { C8_PIN(r.a01[it]); C8_PIN(r.a10[it]); }
+    C8_PIN(r.a11);
+    C8_PIN(r.bold);
     C8_UNROLL
     for (int it = 0; it < NL_::N00; ++it) {
       int const j = lane + 64 * it;
       if (j < 9 * deg) {
         int const i = (j >= n3) + (j >= 2 * n3), jj = j - i * n3, pos = jj / 3, col = jj - 3 * pos;
-        ga.A[0][0][np * 9 + j] = r.a00[it] + sh.acc[pos][i * 4 + col];
+        ga.A[0][0][np * 9 + j] = r.a00[it] + sh.acc(pos)[i * 4 + col];
       }
     }
     C8_UNROLL
@@ -211,16 +348,17 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG>& sh, Mes
       int const j = lane + 64 * it;
       if (j < n3) {
         int const i = (j >= deg) + (j >= 2 * deg), pos = j - i * deg;
-        ga.A[0][1][np * 3 + j] = r.a01[it] + sh.acc[pos][i * 4 + 3];
+        ga.A[0][1][np * 3 + j] = r.a01[it] + sh.acc(pos)[i * 4 + 3];
         int const pos2 = j / 3, col = j - 3 * pos2;
-        ga.A[1][0][np * 3 + j] = r.a10[it] + sh.acc[pos2][3 * 4 + col];
+        ga.A[1][0][np * 3 + j] = r.a10[it] + sh.acc(pos2)[3 * 4 + col];
       }
     }
-    if (lane < deg) ga.A[1][1][np + lane] = r.a11 + sh.acc[lane][15];
-    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] = (ga.assign ? 0. : ga.b[0][(size_t)node * 3 + lane]) + sh.bsum[lane];
-    if (lane == 3) ga.b[1][node] = (ga.assign ? 0. : ga.b[1][node]) + sh.bsum[3];
+    if (lane < deg) ga.A[1][1][np + lane] = r.a11 + sh.acc(lane)[15];
+    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] = r.bold + sh.bsum[lane];
+    if (lane == 3) ga.b[1][node] = r.bold + sh.bsum[3];
   });
   ex.sync();
+  C8_NSTAMP(5);
 }
 
 }  // namespace c8

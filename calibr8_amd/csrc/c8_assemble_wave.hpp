@@ -918,6 +918,7 @@ template <class E, int MAXDEG> struct GatherLane {
   double v[CH][NLD], rv[CH];
   int pos[CH][NLD];
   double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
+  double bold;                               // ... and of its residual entry (lanes 0..3)
   double rsum;
 };
 
@@ -954,6 +955,8 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
     }
     r.a11 = 0.;
     if (!ga.assign && lane < deg) r.a11 = ga.A[1][1][np + lane];
+    r.bold = 0.;
+    if (!ga.assign && lane < 4) r.bold = lane < 3 ? ga.b[0][(size_t)node * 3 + lane] : ga.b[1][node];
     constexpr int LDA = GatherShared<E, MAXDEG>::LD;
     C8_UNROLL
     for (int it = 0; it < (MAXDEG * LDA + 63) / 64; ++it) {
@@ -1013,6 +1016,15 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
   }
   ex.each([&](int lane) {
     auto& r = ex.lane(lane);
+    // all fetched values complete HERE, once, outside the conditional stores below: with the waits inside the branches the
+    // compiler's count of outstanding memory operations is lost at every join, and it then drains the counter -- the
+    // previous store included -- in front of each store
+    C8_UNROLL
+    for (int it = 0; it < GL::N00; ++it) C8_PIN(r.a00[it]);
+    C8_UNROLL
+    for (int it = 0; it < GL::N01; ++it) { C8_PIN(r.a01[it]); C8_PIN(r.a10[it]); }
+    C8_PIN(r.a11);
+    C8_PIN(r.bold);
     C8_UNROLL
     for (int it = 0; it < GL::N00; ++it) {
       int const j = lane + 64 * it;
@@ -1032,8 +1044,8 @@ C8_HD void gather_node_rows(EX& ex, GatherShared<E, MAXDEG>& sh, GatherArgs cons
       }
     }
     if (lane < deg) ga.A[1][1][np + lane] = r.a11 + sh.acc[lane][15];
-    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] = (ga.assign ? 0. : ga.b[0][(size_t)node * 3 + lane]) + r.rsum;
-    if (lane == 3) ga.b[1][node] = (ga.assign ? 0. : ga.b[1][node]) + r.rsum;
+    if (lane < 3) ga.b[0][(size_t)node * 3 + lane] = r.bold + r.rsum;
+    if (lane == 3) ga.b[1][node] = r.bold + r.rsum;
   });
   ex.sync();
 }

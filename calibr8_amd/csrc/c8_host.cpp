@@ -50,6 +50,8 @@ std::string build_node_graph(HostMesh const& m, HostGraph& g) {
   if (nn > 8 || m.nelems >= (1 << 28)) return "node-to-element table needs nn <= 8 and fewer than 2^28 elements";
   g.nodeelem_ptr.assign((size_t)m.nnodes + 1, 0);
   for (size_t q = 0; q < m.conn.size(); ++q) g.nodeelem_ptr[(size_t)m.conn[q] + 1]++;
+  g.max_node_elems = 0;
+  for (int n = 0; n < m.nnodes; ++n) g.max_node_elems = std::max(g.max_node_elems, (int)g.nodeelem_ptr[n + 1]);
   for (int n = 0; n < m.nnodes; ++n) g.nodeelem_ptr[n + 1] += g.nodeelem_ptr[n];
   g.nodeelem.assign(m.conn.size(), 0);
   {

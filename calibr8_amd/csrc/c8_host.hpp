@@ -30,6 +30,7 @@ struct HostGraph {
   std::vector<int32_t> nodeelem_ptr;  // [nnodes+1] offsets into nodeelem
   std::vector<int32_t> nodeelem;      // elements of a node, ascending, packed (element << 3) | local node index
   int max_degree = 0;                 // longest row of the node graph
+  int max_node_elems = 0;             // most elements around one node
 };
 
 // Node-to-node graph with sorted rows, plus the per-element position table.

@@ -54,6 +54,9 @@ template <class Lane> struct GpuExec {
     else *p += v;
   }
   __device__ __forceinline__ void flag(int* s) { atomicOr(s, 1); }
+  // *p += v for p in LDS, without a return value: ds_add_f64, no vector ALU instruction.  Adds of one wavefront to one
+  // address take effect in program order.
+  __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
   // get(l) evaluated in lane S of the caller's group of 8 lanes (lanes 8g .. 8g+7), returned to every lane of the
   // group: two DPP row broadcasts (lane S and lane 8+S of each row of 16) and a select per 32-bit half, no LDS and no
   // barrier.  The source lane must be active whenever a reader is (a group is active or inactive as a whole wherever
@@ -83,6 +86,13 @@ template <class Lane> struct GpuExec {
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
   }
 #ifdef C8_STAMPS
+  // row-per-node kernel: node n is sampled when n % 244 == 0; the stamp does not wait for outstanding memory operations
+  __device__ __forceinline__ void stamp_node(unsigned long long* stamps, int n, int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    if (k == 0 && stamps && (n % 244) == 0 && n / 244 < 4096) stamps[(size_t)(n / 244) * 16 + i] = t;
+  }
   // element e is sampled when e % 244 == 0 (4096 samples over a 1M-element mesh)
   __device__ __forceinline__ void stamp(SystemArgs const& sa, int e, int i) {
     __builtin_amdgcn_sched_barrier(0);
@@ -420,29 +430,31 @@ template <class E> static hipError_t launch_gather_rows(GatherArgs const& ga, in
 // and written once -- no element stage.  Contiguous eighths of the node order per XCD: neighbouring nodes share their
 // elements' shape tables and state in one L2.
 #ifndef C8_NODE_WAVES
-#define C8_NODE_WAVES 2
+#define C8_NODE_WAVES 3
 #endif
-template <class E, template <class> class ModelT, int MAXDEG>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C8_NODE_WAVES, 4)))
+template <class E, template <class> class ModelT, int MAXDEG, bool MANY>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MANY ? 2 : C8_NODE_WAVES, 4)))
 k_node_rows_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, GatherArgs ga, int first, int count, int nblocks) {
   using Lane = NodeLane<MAXDEG>;
-  __shared__ NodeShared<E, ModelT<Dual>, MAXDEG> sh;
+  __shared__ NodeShared<E, ModelT<Dual>, MAXDEG, MANY> sh;
   int const lb = xcd_block(blockIdx.x, nblocks);
   if (lb >= nblocks || lb >= count) return;
   Lane L;
   GpuExec<Lane> ex(threadIdx.x, L);
-  node_rows_closed<E, ModelT, MAXDEG>(ex, sh, mt, ms, fa, ga, ga.node_order[first + lb]);
+  node_rows_closed<E, ModelT, MAXDEG, MANY>(ex, sh, mt, ms, fa, ga, first + lb);  // nodes [first, first + count)
 }
+// max_node_elems <= 8 (every hex8 mesh cut out of a structured one, most others): the lean form; otherwise a node's
+// elements go through the kernel eight at a time
 template <class E, template <class> class ModelT>
 static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms, FieldArgs const& fa, GatherArgs const& ga,
-                                   int first, int count, int max_degree, hipStream_t stream) {
+                                   int first, int count, int max_degree, int max_node_elems, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   int const nblocks = count;
   int const grid = ((nblocks + 7) / 8) * 8;
-  if (max_degree <= 32)
-    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, 32>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
+  if (max_degree <= 32 && max_node_elems <= 8)
+    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, 32, false>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
   else if (max_degree <= GATHER_MAX_DEGREE)
-    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, GATHER_MAX_DEGREE>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
+    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, true>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -26,7 +26,7 @@ struct LaunchArgs {
 typedef hipError_t (*LaunchFn)(LaunchArgs const&);
 typedef hipError_t (*GatherFn)(GatherArgs const&, int first, int count, int max_degree, hipStream_t);
 typedef hipError_t (*NodeRowsFn)(MeshTables const&, ModelSettings const&, FieldArgs const&, GatherArgs const&, int first, int count,
-                                 int max_degree, hipStream_t);
+                                 int max_degree, int max_node_elems, hipStream_t);
 
 struct KernelSet {
   LaunchFn forward_jacobian;   // K1, one lane group (NDOF lanes) per element

@@ -324,28 +324,29 @@ template <class T, int DIM> struct SmallJ2Dim {
   // closed_form_row gathers what depends on the point and the ROW node only (NROW doubles), closed_form_block adds the block
   // of one column node: 57 operations per point and node pair, no selects.
   static constexpr bool HAS_CLOSED_FORM_ROWS = HAS_CLOSED_FORM;
-  static constexpr int NROW = 17;
-  // r: w g (3) | w b (n g) (3) | a/2 | -a/3 | n' (xx xy xz yy yz zz) | w N_a | w N_a / kappa | tau
-  C8_HD static void closed_form_row(double const* t, double w, double const* g, double Na, double* r) {
-    double const a = t[0], b = t[1], trn3 = t[2], inv_kappa = t[3], tau = t[4];
+  static constexpr int NROW = 14;
+  // r: w g (3) | w b (n g) (3) | a/2 | w N_a | n' (xx xy xz yy yz zz);   el (the same at every point of an element): tau, 1/kappa
+  C8_HD static void closed_form_row(double const* t, double w, double const* g, double Na, double* r, double* el) {
+    double const a = t[0], b = t[1], trn3 = t[2];
     double const* n = t + 5;
     r[0] = w * g[0]; r[1] = w * g[1]; r[2] = w * g[2];
     double const wb = w * b;
     C8_UNROLL
     for (int i = 0; i < 3; ++i) r[3 + i] = wb * (n[3 * i] * g[0] + n[3 * i + 1] * g[1] + n[3 * i + 2] * g[2]);
     r[6] = 0.5 * a;
-    r[7] = -(a * (1. / 3.));
+    r[7] = w * Na;
     r[8] = n[0] - trn3; r[9] = n[1]; r[10] = n[2]; r[11] = n[4] - trn3; r[12] = n[5]; r[13] = n[8] - trn3;
-    double const wN = w * Na;
-    r[14] = wN; r[15] = wN * inv_kappa; r[16] = tau;
+    el[0] = t[4];
+    el[1] = t[3];
   }
   // J[4 i + k] += block entry (row i of the row node, column k of the column node; 3 = p)
-  C8_HD static void closed_form_block(double const* r, double const* h, double Nm, double* J) {
+  C8_HD static void closed_form_block(double const* r, double const* el, double const* h, double Nm, double* J) {
     double const gh = r[0] * h[0] + r[1] * h[1] + r[2] * h[2];
     double const nh[3] = {r[8] * h[0] + r[9] * h[1] + r[10] * h[2], r[9] * h[0] + r[11] * h[1] + r[12] * h[2],
                           r[10] * h[0] + r[12] * h[1] + r[13] * h[2]};
     double const p1[3] = {r[6] * r[0], r[6] * r[1], r[6] * r[2]};   // a/2 w g_k
-    double const p2[3] = {r[7] * h[0], r[7] * h[1], r[7] * h[2]};   // -a/3 h_k
+    double const m3 = r[6] * (-2. / 3.);                               // -a/3
+    double const p2[3] = {m3 * h[0], m3 * h[1], m3 * h[2]};
     C8_UNROLL
     for (int i = 0; i < 3; ++i)
       C8_UNROLL
@@ -355,8 +356,8 @@ template <class T, int DIM> struct SmallJ2Dim {
     C8_UNROLL
     for (int i = 0; i < 3; ++i) J[4 * i + 3] = fma(-r[i], Nm, J[4 * i + 3]);
     C8_UNROLL
-    for (int k = 0; k < 3; ++k) J[12 + k] = fma(-r[14], h[k], J[12 + k]);
-    J[15] = fma(-r[16], gh, fma(-r[15], Nm, J[15]));
+    for (int k = 0; k < 3; ++k) J[12 + k] = fma(-r[7], h[k], J[12 + k]);
+    J[15] = fma(-el[0], gh, fma(-(r[7] * el[1]), Nm, J[15]));
   }
 };
 template <class T> struct SmallJ2 : SmallJ2Dim<T, 3> {};       // "small_J2" on a 3-D mesh

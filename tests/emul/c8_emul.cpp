@@ -36,6 +36,7 @@ template <class Lane, int NDOF> struct CpuExec {
   void sync() {}
   void add(double* p, double v, int) { *p += v; }
   void flag(int* s) { *s = 1; }
+  void lds_add(double* p, double v) { *p += v; }
   // the value of get() in lane S of the caller's group of 8 lanes (GpuExec: DPP broadcast).  Sound in this serial
   // emulation only where lane S does not change the value during the same each(): true for the pivot column of an
   // elimination step, which its owner leaves alone in that step.
@@ -107,6 +108,8 @@ extern "C" void c8emu_qoi_info(double* out) { out[0] = g_qoi.area; out[1] = g_qo
 
 static int g_shape_cache = 1;  // the wave kernels read cached shape tables (c8_set_shape_cache) or compute them per call
 extern "C" void c8emu_set_shape_cache(int on) { g_shape_cache = on; }
+static int g_node_many = 0;  // row-per-node kernel: the form with separate accumulator storage also where no node has more than eight elements
+extern "C" void c8emu_set_node_many(int on) { g_node_many = on; }
 static int g_last_nchunks = 0;
 extern "C" int c8emu_last_nchunks() { return g_last_nchunks; }
 
@@ -238,22 +241,25 @@ template <template <class> class ModelT> static void run_wave(Call const& c) {
 // K1, one wavefront per node (c8_assemble_node.hpp): every node that has elements, in ascending order -- or, with
 // c.staged set, the upper half of the nodes first and the lower half afterwards, as the two-part form of the library does
 // (c8_set_gather_early_nodes + c8_gather_finish)
-template <template <class> class ModelT> static int run_node_rows(Call const& c) {
+template <template <class> class ModelT, bool MANY> static void run_node_rows_as(Call const& c) {
   using E = Elem<C8_HEX8>;
+  auto* sh = new NodeShared<E, ModelT<Dual>, GATHER_MAX_DEGREE, MANY>();
+  auto* ex = new CpuExec<NodeLane<GATHER_MAX_DEGREE>, 64>();
+  GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), nullptr, 0, nullptr,
+                {{c.sa.A[0][0], c.sa.A[0][1]}, {c.sa.A[1][0], c.sa.A[1][1]}}, {c.sa.b[0], c.sa.b[1]}, c.assign};
+  auto one = [&](int n) { node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, MANY>(*ex, *sh, c.mt, c.ms, c.fa, ga, n); };
+  int const half = c.staged ? c.nnodes / 2 : 0;
+  for (int n = half; n < c.nnodes; ++n) one(n);
+  for (int n = 0; n < half; ++n) one(n);
+  delete ex;
+  delete sh;
+}
+template <template <class> class ModelT> static int run_node_rows(Call const& c) {
   if constexpr (has_closed_form_rows<ModelT<Dual>>::value) {
     if (!c.mt.shape || c.graph->max_degree > GATHER_MAX_DEGREE) return -4;
-    auto* sh = new NodeShared<E, ModelT<Dual>, GATHER_MAX_DEGREE>();
-    auto* ex = new CpuExec<NodeLane<GATHER_MAX_DEGREE>, 64>();
-    GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), nullptr, 0, nullptr,
-                  {{c.sa.A[0][0], c.sa.A[0][1]}, {c.sa.A[1][0], c.sa.A[1][1]}}, {c.sa.b[0], c.sa.b[1]}, c.assign};
-    auto one = [&](int n) {
-      if (c.graph->nodeelem_ptr[n + 1] > c.graph->nodeelem_ptr[n]) node_rows_closed<E, ModelT, GATHER_MAX_DEGREE>(*ex, *sh, c.mt, c.ms, c.fa, ga, n);
-    };
-    int const half = c.staged ? c.nnodes / 2 : 0;
-    for (int n = half; n < c.nnodes; ++n) one(n);
-    for (int n = 0; n < half; ++n) one(n);
-    delete ex;
-    delete sh;
+    // the library's choice (launch_node_rows); g_node_many forces the form for nodes with more than eight elements
+    if (c.graph->max_node_elems > 8 || g_node_many) run_node_rows_as<ModelT, true>(c);
+    else run_node_rows_as<ModelT, false>(c);
     return 0;
   } else {
     return -4;
