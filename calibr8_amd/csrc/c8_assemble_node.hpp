@@ -68,6 +68,9 @@ template <class E, class ModelD, int MAXDEG, bool MANY> struct NodeShared {
 #define C8_TUNE_NODE_PREFETCH 0
 #endif
 constexpr int NODE_PFN = C8_TUNE_NODE_PREFETCH;
+#ifndef C8_TUNE_NODE_HAHEAD
+#define C8_TUNE_NODE_HAHEAD 3
+#endif
 
 template <int MAXDEG> struct NodeLane {
   static constexpr int N00 = (9 * MAXDEG + 63) / 64, N01 = (3 * MAXDEG + 63) / 64;
@@ -247,23 +250,29 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       double const* const t = mt.shape + (size_t)r.e * SHAPE_STRIDE;
       HexShape<E> const Nn = HexShape<E>::of_node(m);
       double const el[2] = {sh.el[s][0], sh.el[s][1]};
-      // dN_m/dx of this lane's column node, one point ahead of the arithmetic (the element's table is in L1 / L2 by now)
-      double hc[3] = {t[m * 3 + 0], t[m * 3 + 1], t[m * 3 + 2]};
+      // dN_m/dx of this lane's column node, C8_TUNE_NODE_HAHEAD points ahead of the arithmetic (the element's table is in
+      // L1 / L2 by now)
+      constexpr int AH = C8_TUNE_NODE_HAHEAD;
+      double hq[AH + 1][3];
+      C8_UNROLL
+      for (int k = 0; k < AH; ++k) { hq[k][0] = t[(k * E::NN + m) * 3 + 0]; hq[k][1] = t[(k * E::NN + m) * 3 + 1]; hq[k][2] = t[(k * E::NN + m) * 3 + 2]; }
       C8_UNROLL
       for (int pt = 0; pt < E::NP0; ++pt) {
-        double hn[3] = {0., 0., 0.};
-        if (pt + 1 < E::NP0) {
-          hn[0] = t[((pt + 1) * E::NN + m) * 3 + 0];
-          hn[1] = t[((pt + 1) * E::NN + m) * 3 + 1];
-          hn[2] = t[((pt + 1) * E::NN + m) * 3 + 2];
+        hq[AH][0] = hq[AH][1] = hq[AH][2] = 0.;
+        if (pt + AH < E::NP0) {
+          hq[AH][0] = t[((pt + AH) * E::NN + m) * 3 + 0];
+          hq[AH][1] = t[((pt + AH) * E::NN + m) * 3 + 1];
+          hq[AH][2] = t[((pt + AH) * E::NN + m) * 3 + 2];
         }
+        double const hc[3] = {hq[0][0], hq[0][1], hq[0][2]};
         Model::closed_form_block(sh.rec(s, pt), el, hc, Nn.at_point(pt), r.J);
         // one point's record in registers at a time: without the lines below the compiler fetches the records of all
         // eight points first (over a hundred doubles) and spills
         C8_UNROLL
         for (int j = 0; j < 16; ++j) C8_PIN(r.J[j]);
         C8_SCHED_FENCE();
-        hc[0] = hn[0]; hc[1] = hn[1]; hc[2] = hn[2];
+        C8_UNROLL
+        for (int k = 0; k < AH; ++k) { hq[k][0] = hq[k + 1][0]; hq[k][1] = hq[k + 1][1]; hq[k][2] = hq[k + 1][2]; }
       }
       if (m < 4) {
         double v = 0.;
