@@ -34,7 +34,7 @@ def main():
         d = os.path.join(ROOT, "gpurun_out", "pmc_tmp")
         shutil.rmtree(d, ignore_errors=True)
         cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                                             sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1"] + args.bench_args
+                                             sys.executable, os.path.join(ROOT, "bench.py"), "--headline-only", "--steps", "3", "--warmup", "1"] + args.bench_args
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             print(r.stdout[-2000:], r.stderr[-2000:])
@@ -64,7 +64,7 @@ def main():
     ba = args.bench_args
     opt = lambda name, default: ba[ba.index(name) + 1] if name in ba else default
     scatter, kernel = opt("--scatter", "gather"), opt("--kernel", "auto")
-    kkey = kernel if kernel in ("slot", "wave_ad") else "wave"
+    kkey = kernel if kernel in ("slot", "wave_ad") else ("node" if kernel in ("auto", "node") and scatter == "gather" else "wave")
     out["config"] = {"edge": int(opt("--edge", 100)), "scatter": scatter, "kernel": kkey}
     out["build_id"] = info.split()[0].split("=")[1]
     out["library_build"] = info
@@ -72,12 +72,14 @@ def main():
     fwd = [k for k in out["per_launch_mean"] if "k_forward_jacobian" in k and "SmallJ2" in k]
     fwd = [k for k in fwd if ("_closed" in k) == (kkey == "wave")] or fwd
     rows = [k for k in out["per_launch_mean"] if "k_gather_rows" in k] if scatter == "gather" else []
+    if kkey == "node":  # one kernel forms and writes the rows: no stage, no row-sum launch
+        fwd, rows = [k for k in out["per_launch_mean"] if "k_node_rows_closed" in k], []
     out["launches_per_assembly"] = fwd[:1] + rows[:1]
     ncol = {"colored": 8}.get(scatter, 1)  # per_launch_mean of a colour-batched assembly is the mean over its launches
     if all("hbm_bytes_corrected" in out["per_launch_mean"][k] for k in out["launches_per_assembly"]) and out["launches_per_assembly"]:
         out["traffic_bytes_per_launch"] = sum(out["per_launch_mean"][k]["hbm_bytes_corrected"] for k in out["launches_per_assembly"]) * ncol
-    out["note"] = ("rocprofv3 --pmc passes (one counter group per pass, kernel-trace only) on `python3 bench.py --no-cpu --steps 2 "
-                   "--warmup 1 %s`; traffic_bytes_per_launch = HBM-side bytes per ASSEMBLY = sum over the assembly's kernel "
+    out["note"] = ("rocprofv3 --pmc passes (one counter group per pass, kernel-trace only) on `python3 bench.py --headline-only --steps 3 "
+                   "--warmup 1 %s` (the timed configuration alone: no `also` timings in the profiled process); traffic_bytes_per_launch = HBM-side bytes per ASSEMBLY = sum over the assembly's kernel "
                    "launches of 1024*(2*FETCH_SIZE + WRITE_SIZE): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
                    "gfx950 (an upper bound for our gathers), WRITE_SIZE exact for 16-B stores" % " ".join(ba))
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
