@@ -11,6 +11,39 @@ from meshes import brick, fields_for, jiggle, prescribed_fields
 from parity import compare_systems, rel_csr_rows, rel_vec
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Audit:
+    """Which of the checker's allowances a green run actually used.  The bar is 1e-12 on every quantity, compared DIRECTLY;
+    four allowances exist for cases where the algorithm itself has finite resolution (documented where they are applied):
+      at_state      a Jacobian block / residual above the bar directly, within it against the oracle AT THE DEVICE'S OWN
+                    converged local state
+      xi_10x        the local state above the bar, within ten times the local Newton tolerance (only after at_state)
+      ulp_sens      an entry above the bar, within four times the oracle's own deviation under a one-ulp input change
+      k3_rhs_scale  the adjoint right-hand side above the bar against its own norm, within it against its largest summand
+    Every use is counted per (context, model, allowance); the models of BASELINE.json's configurations and their elastic
+    companions (STRICT) must pass with none: for them "within 1e-12" is the direct comparison, nothing else."""
+    STRICT = ("elastic", "small_J2", "small_hill", "isotropic_elastic")
+
+    def __init__(self):
+        from collections import Counter
+        self.used, self.cases, self.ctx = Counter(), Counter(), "unset"
+
+    def case(self, model, what):
+        self.cases["%s|%s|%s" % (self.ctx, model, what)] += 1
+
+    def fire(self, model, allowance, detail=None):
+        self.used["%s|%s|%s" % (self.ctx, model, allowance)] += 1
+        assert model not in self.STRICT, "allowance %s used for %s (%s): %r -- this model must meet the bar directly" % (allowance, model, self.ctx, detail)
+
+    def table(self):
+        return {"cases": dict(self.cases), "allowances_used": dict(self.used), "strict_models": list(self.STRICT)}
+
+    def dump(self, path):
+        json.dump(self.table(), open(path, "w"), indent=1, sort_keys=True)
+
+
+AUDIT = Audit()
 J2 = [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0]
 HJ2 = [1000.0, 0.25, 2.0, 1.0, 5.0, 0.5, 0.5, 100.0]
 EL = [1000.0, 0.25, 1e-3, 10.0]
@@ -105,9 +138,9 @@ def forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip):
     deviations with every A block replaced by min(direct, at-the-same-state), plus both under their own names."""
     errs = compare_systems(orc, ls_d, ls_o)
     errs["xi"] = rel_vec(xd, xo)
-    direct = max(errs["A%d%d" % (i, j)] for i in range(2) for j in range(2))
+    direct = max(max(errs["A%d%d" % (i, j)] for i in range(2) for j in range(2)), errs["b_u"], errs["b_p"])  # the direct comparison
     same = None
-    if direct > 1e-13 or errs["xi"] > 1e-13:
+    if max(errs["A%d%d" % (i, j)] for i in range(2) for j in range(2)) > 1e-13 or errs["xi"] > 1e-13:
         A_at = jacobian_at_state(orc, u, p, up, pp, xip, xd)
         same = {}
         for i in range(2):
@@ -149,6 +182,9 @@ def check_forward(orc, dut, c, model, eps, tol):
         assert orc.forward_jacobian(u, p, up, pp, xip, xo, ls_o) == 0
         assert dut.forward_jacobian(u, p, up, pp, xip, xd, ls_d) == 0
         errs, direct, same = forward_errors(orc, ls_d, xd, ls_o, xo, u, p, up, pp, xip)
+        AUDIT.case(model, "forward")
+        if direct >= tol and max(errs.values()) < tol:
+            AUDIT.fire(model, "at_state", (direct, same))
         # the local state agrees to `tol`, or -- when system and state have been checked against each other at the
         # device's own state -- to ten times the local Newton tolerance (the iteration's own resolution)
         xi_err = errs.pop("xi")
@@ -157,7 +193,10 @@ def check_forward(orc, dut, c, model, eps, tol):
             assert orc.forward_jacobian(ulp_perturbed(u), p, up, pp, xip, orc.new_state(), ls_p) == 0
             bad = bar_with_sensitivity(errs, tol, compare_systems(orc, ls_p, ls_o))
             assert not bad, (n, bad, errs, direct, same, xi_err)
+            AUDIT.fire(model, "ulp_sens", errs)
         assert xi_err < tol or (same is not None and xi_err < 10.0 * getattr(orc, "local_abs_tol", 1e-12)), (n, xi_err, errs)
+        if xi_err >= tol:
+            AUDIT.fire(model, "xi_10x", xi_err)
     if model == "small_J2" and eps > 0.003:
         assert (st[2][2][:, :, -1] > 0).mean() > 0.3  # the plastic branch really ran (alpha is the last local unknown)
 
@@ -194,17 +233,22 @@ def check_adjoint_chain(orc, dut, c, model, eps, tol):
         assert dut.adjoint_jacobian(u, p, up, pp, xip, xi, g_d, f_d, ls_d) == 0
         errs = compare_systems(orc, ls_d, ls_o)
         errs["g"] = rel_vec(g_d, g_o)
+        AUDIT.case(model, "adjoint")
         # the right-hand side is a sum over elements of entries of the history f (among others): judged against the
         # largest summand, not against the sum (with the stand-in adjoint solution below the summands cancel by three
         # orders of magnitude: |f| ~ 20, |b| ~ 0.02; the order of the scatter then shows at 4e-12 of |b|)
+        unscaled = max(errs["b_u"], errs["b_p"])
         for i, k in enumerate(("b_u", "b_p")):
             top = np.abs(ls_o.b[i]).max()
             errs[k] *= top / max(top, np.abs(f_in).max()) if top > 0 else 1.0
+        if unscaled >= tol and max(errs["b_u"], errs["b_p"]) < tol:
+            AUDIT.fire(model, "k3_rhs_scale", unscaled)
         if max(errs.values()) >= tol:
             ls_p = orc.new_linsys()
             orc.adjoint_jacobian(ulp_perturbed(u), p, up, pp, xip, xi, g_in.copy(), f_in, ls_p)
             bad = bar_with_sensitivity(errs, tol, compare_systems(orc, ls_p, ls_o))
             assert not bad, ("adjoint_jacobian", n, bad, errs)
+            AUDIT.fire(model, "ulp_sens", errs)
         # a stand-in global adjoint solution (the linear solve is out of scope)
         z_u = rng.standard_normal(len(u)) * 1e-3
         z_p = rng.standard_normal(len(p)) * 1e-3
@@ -257,9 +301,10 @@ def check_two_element_sets(factory, kind, tol, wave=None):
     z_u, z_p = rng.standard_normal(len(u)) * 1e-3, rng.standard_normal(len(p)) * 1e-3
     phi = np.zeros_like(g)
     orc.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
-    gr_o = orc.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
+    gr_o, gr_scale = orc.qoi_gradient_with_scale(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
     gr_d = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
-    assert np.abs(gr_o).min() > 0 and (np.abs(gr_d - gr_o) / np.abs(gr_o)).max() < 1e-11, (gr_d, gr_o)
+    # per component at `tol` against the sum of the magnitudes of the products summed into it (see check_adjoint_chain)
+    assert np.abs(gr_o).min() > 0 and (np.abs(gr_d - gr_o) / np.maximum(gr_scale, 1e-300)).max() < tol, (gr_d, gr_o, gr_scale)
 
 
 def check_tiny_and_ragged(factory, tol):

@@ -80,3 +80,81 @@ def test_product_does_not_reference_the_oracle_or_emulator():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in text and "libc8oracle" not in text and "c8o_" not in text, f
                 assert "libc8emul" not in text and "emul_lib" not in text, f
+
+
+# ---- compiled clients of include/c8.h (tests/abi_client): the boundary without ctypes -------------------------------------
+ABI_OUT = "/tmp/c8_abi_client"
+
+
+def _build_abi_clients():
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "abi_client"), "-s", "OUT=" + ABI_OUT])
+
+
+def test_header_compiles_as_c_and_cpp_and_matches_the_ctypes_mirror():
+    """include/c8.h compiled by gcc -std=c11 and g++ -std=c++17 (-pedantic -Werror): sizeof / offsetof of every struct and
+    the enum values, compared with calibr8_amd/lib.py -- the layouts every GPU test relies on through ctypes."""
+    import json
+    import subprocess
+    from calibr8_amd import lib
+    _build_abi_clients()
+    c_layout = json.loads(subprocess.check_output([os.path.join(ABI_OUT, "layout_c")]))
+    cpp_layout = json.loads(subprocess.check_output([os.path.join(ABI_OUT, "layout_cpp")]))
+    assert c_layout == cpp_layout
+    mirror = {"c8_mesh_desc": lib.MeshDesc, "c8_model_desc": lib.ModelDesc, "c8_state": lib.State, "c8_system": lib.System,
+              "c8_calibration_desc": lib.CalibrationDesc, "c8_dbc": lib.Dbc, "c8_tbc": lib.Tbc, "c8_newton_opts": lib.NewtonOpts,
+              "c8_halo_desc": lib.HaloDesc, "c8_lbfgs_opts": lib.LbfgsOpts, "c8_lbfgs_result": lib.LbfgsResult}
+    structs = {k: v for k, v in c_layout.items() if k != "enums"}
+    assert sorted(structs) == sorted(mirror)  # every struct of the header has a mirror and the other way round
+    for name, cls in mirror.items():
+        lay = structs[name]
+        assert C.sizeof(cls) == lay["sizeof"], name
+        fields = [f for f in lay if f != "sizeof"]
+        assert fields == [f[0] for f in cls._fields_], (name, fields)  # same members, same order
+        for f in fields:
+            assert getattr(cls, f).offset == lay[f], (name, f)
+    for k, v in c_layout["enums"].items():
+        assert getattr(lib, k) == v, k
+    # the clients that run on the GPU box link against libc8.so here (no device needed to link)
+    assert os.path.exists(os.path.join(ABI_OUT, "client_c")) and os.path.exists(os.path.join(ABI_OUT, "client_cpp"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary", ["client_c", "client_cpp"])
+def test_compiled_client_matches_the_python_path_bitwise(binary, tmp_path):
+    """tests/abi_client/abi_client.c (C11 and C++17 builds): c8_create -> c8_assemble_forward_jacobian (twice) ->
+    c8_assemble_residual -> c8_halo_build / attach / gather / scatter_x -> c8_comm_allreduce_sum, straight through the C ABI;
+    the same inputs through calibr8_amd.Assembler give the same bits."""
+    import subprocess
+    import torch
+    import calibr8_amd
+    _build_abi_clients()
+    out = str(tmp_path / "abi.bin")
+    msg = subprocess.check_output([os.path.join(ABI_OUT, binary), out]).decode()
+    assert msg.startswith("abi_client ok")
+    raw = np.fromfile(out)
+    nnodes, nelems = int(raw[0]), int(raw[1])
+    nnz = [int(v) for v in raw[2:6]]
+    nx, ny = int(raw[6]), int(raw[7])
+    nz = nelems // (nx * ny)
+    ofs = [8]
+    for n in [3 * nnodes, nnodes] + nnz + [3 * nnodes, nnodes, nelems * 8 * 7]:
+        ofs.append(ofs[-1] + n)
+    assert ofs[-1] == len(raw)
+    part = [raw[ofs[k]:ofs[k + 1]] for k in range(len(ofs) - 1)]
+    u_h, p_h, A, b, xi_c = part[0], part[1], part[2:6], part[6:8], part[8]
+    c, conn = calibr8_amd.brick_mesh(nx, ny, nz, 1.0, 0.8, 0.6)
+    asm = calibr8_amd.Assembler(8, c, conn, "small_J2", [1000.0, 0.25, 100.0, 2.0, 0.0, 0.0])
+    assert [asm.nnz[i][j] for i in range(2) for j in range(2)] == nnz
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    ls, xi = asm.new_linsys(), asm.new_state()
+    z, zp = torch.zeros_like(u), torch.zeros_like(p)
+    for _ in range(2):
+        assert asm.forward_jacobian(u, p, z, zp, asm.new_state(), xi, ls) == 0
+    assert asm.global_residual(u, p, z, zp, asm.new_state(), xi, ls) == 0
+    torch.cuda.synchronize()
+    for k, (i, j) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        assert np.array_equal(ls.A[i][j].cpu().numpy(), A[k]) and np.abs(A[k]).max() > 0
+    for i in range(2):
+        assert np.array_equal(ls.b[i].cpu().numpy(), b[i]) and np.abs(b[i]).max() > 0
+    assert np.array_equal(xi.cpu().numpy().ravel(), xi_c) and (xi_c.reshape(-1, 7)[:, 6] > 0).any()

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as ol
 from meshes import brick, jiggle
-from parity_cases import ACTIVE, CASES, check_adjoint_chain, check_forward, check_residual
+from parity_cases import ACTIVE, AUDIT, CASES, check_adjoint_chain, check_forward, check_residual
 
 pytestmark = pytest.mark.gpu
 PARAMS = {m: p for m, p, _ in CASES}
@@ -28,7 +28,12 @@ def random_case(seed):
         assert (vol > 0).all()
     eps = float(10 ** rng.uniform(-3.3, -2.2))
     scatter = ["colored", "atomic", "gather"][rng.integers(3)]
-    kernel = ["auto", "slot"][rng.integers(2)] if kind == "hex8" else "auto"
+    # hex8: the library's choice, the lane-group kernel, the wave kernel with the iterated AD form (what every model without a
+    # closed form runs), and for small_J2 also its two closed-form kernels by name (staged wave kernel; row-per-node kernel)
+    kernels = ["auto", "slot", "wave_ad"] if kind == "hex8" else ["auto"]
+    if kind == "hex8" and model == "small_J2":
+        kernels += ["wave"] + (["node"] if scatter == "gather" else [])
+    kernel = kernels[rng.integers(len(kernels))]
     # perturbed parameters (+-20 %), kept admissible
     p = np.array(PARAMS[model], dtype=np.float64)
     p = p * (1.0 + 0.2 * (rng.random(len(p)) - 0.5) * (np.abs(p) > 0))
@@ -49,6 +54,7 @@ def test_random_case_matches_oracle(seed):
     # with the oracle's Jacobian AT THE SAME converged local state (the states themselves agree to 1e-15), and a
     # parameter-gradient component against the sum of the magnitudes of the products summed into it.
     tol = 1e-12
+    AUDIT.ctx = "gpu %s %s %s" % (kind, kernel, scatter)
     check_forward(orc, gpu, c, model, eps, tol)
     check_residual(orc, gpu, c, eps, tol)
     if not (kind == "hex8" and kernel == "slot" and scatter == "gather"):  # that adjoint kernel cannot stage (refused)
@@ -95,6 +101,7 @@ def run_case_r2(factory, seed, tol=1e-12):
     if ls:
         orc.set_local_line_search(*LOCAL_LINE_SEARCH)
     dut = factory(et, c, conn, model, params, scatter, LOCAL_LINE_SEARCH if ls else None)
+    AUDIT.ctx = "%s elem%d %s" % (type(dut).__name__, et, scatter)
     check_forward(orc, dut, c, model, eps, tol)
     check_residual(orc, dut, c, eps, tol)
     check_adjoint_chain(orc, dut, c, model, eps, tol)
