@@ -335,8 +335,9 @@ int c8_gather_finish(c8_ctx* c) {
   if (c->pending_node_rows) {
     c->pending_node_rows = false;
     MeshTables const mt{c->d_conn, c->d_coords, c->d_nodeptr, c->d_pos, c->d_elem_set, nullptr, c->d_params, c->d_shape};
-    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, c->pending_ga, 0, c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
-    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, c->pending_ga, c->early_end, c->mesh.nnodes - c->early_end, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+    AdjointArgs const* const paa = c->pending_adjoint ? &c->pending_aa : nullptr;
+    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, paa, c->pending_ga, 0, c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+    C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, paa, c->pending_ga, c->early_end, c->mesh.nnodes - c->early_end, c->graph.max_degree, c->graph.max_node_elems, c->stream));
     return C8_OK;
   }
   int const total = (int)c->plan.node_order.size();
@@ -424,7 +425,7 @@ static bool node_rows_applies(c8_ctx const* c, FieldArgs const& fa) {
 }
 // nodes [0, nnodes) in one launch; with an early node range set, that range now and the two ranges around it in
 // c8_gather_finish (the kernel takes a contiguous range of node numbers: no order table between the launch and the node)
-static int run_node_rows(c8_ctx* c, FieldArgs const& fa, SystemArgs const& sa) {
+static int run_node_rows(c8_ctx* c, FieldArgs const& fa, SystemArgs const& sa, AdjointArgs const* aa = nullptr) {
   if (c->gather_pending) return fail(C8_ERR_ARG, "row-per-node assembly: c8_gather_finish has not been called for the previous assembly");
   GatherArgs ga{c->d_nodeptr, c->d_pos, c->d_nodeelem_ptr, c->d_nodeelem, nullptr, 0, nullptr,
                 {{sa.A[0][0], sa.A[0][1]}, {sa.A[1][0], sa.A[1][1]}}, {sa.b[0], sa.b[1]}, c->assign_mode};
@@ -434,14 +435,16 @@ static int run_node_rows(c8_ctx* c, FieldArgs const& fa, SystemArgs const& sa) {
   ga.stamps = c->d_stamps;
 #endif
   if (c->early_end > c->early_begin) {  // two parts: the early rows now, the rest in c8_gather_finish
-    C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, c->early_begin, c->early_end - c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+    C8_HIP(c->ks.node_rows(mt, c->ms, fa, aa, ga, c->early_begin, c->early_end - c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
     c->pending_ga = ga;
     c->pending_fa = fa;
+    c->pending_adjoint = aa != nullptr;
+    if (aa) c->pending_aa = *aa;
     c->pending_node_rows = true;
     c->gather_pending = true;
     return C8_OK;  // the closed form has no failing local solve: nothing to read back
   }
-  C8_HIP(c->ks.node_rows(mt, c->ms, fa, ga, 0, c->mesh.nnodes, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+  C8_HIP(c->ks.node_rows(mt, c->ms, fa, aa, ga, 0, c->mesh.nnodes, c->graph.max_degree, c->graph.max_node_elems, c->stream));
   return C8_OK;
 }
 
@@ -533,6 +536,9 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
   if (c->kernel_variant == C8_KERNEL_NODE && fn == c->ks.forward_jacobian_wave && !(staged && node_rows_applies(c, fa)))
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": C8_KERNEL_NODE needs C8_SCATTER_GATHER, the shape-table cache and distinct xi / xi_prev arrays");
   if (staged && fn == c->ks.forward_jacobian_wave && node_rows_applies(c, fa)) return run_node_rows(c, fa, sa);
+  // the adjoint assembly in the same form, for the objective whose point integrand has a closed derivative (average
+  // displacement); the calibration objective keeps the dual-number kernel
+  if (staged && fn == c->ks.adjoint_jacobian_wave && node_rows_applies(c, fa) && c->qoi_kind == 0) return run_node_rows(c, fa, sa, &aa);
   if (staged) {
     int const rc = run_staged(c, fn, fa, aa, sa);
     if (rc == C8_ERR_DEVICE && c->scatter_auto && !c->d_stage && !c->assign_mode && c->early_end <= c->early_begin) {

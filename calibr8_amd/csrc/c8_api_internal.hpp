@@ -54,8 +54,9 @@ struct c8_ctx {
   bool gather_pending = false;
   c8::GatherArgs pending_ga{};
   // row-per-node forward assembly (C8_KERNEL_NODE) in two parts: the fields the second part reads
-  bool pending_node_rows = false;
+  bool pending_node_rows = false, pending_adjoint = false;
   c8::FieldArgs pending_fa{};
+  c8::AdjointArgs pending_aa{};
   double* d_shape = nullptr;          // cached shape tables of the wave kernels, [nelems][ks.shape_stride] (hex8; null: computed per call)
   double* d_params = nullptr;
   int32_t* d_active = nullptr;  // [nsets][10]: {grad offset, n_active, indices...}

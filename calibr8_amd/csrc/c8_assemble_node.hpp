@@ -111,9 +111,14 @@ template <class E> struct HexShape {
   }
 };
 
-template <class E, template <class> class ModelT, int MAXDEG, bool MANY, class EX>
+// ADJ = false: eval_forward_jacobian (evaluations.cpp:12-154): A += dR/dx, b += R, xi = the converged local state.
+// ADJ = true:  eval_adjoint_jacobian (evaluations.cpp:349-526) for the objective "average displacement": A += (dR/dx)^T at
+//              the stored state, b += -dJ/dx + f + (dxi/dx)^T g; g is left as it is (dJ/dxi = 0 for this objective) and
+//              no state is written.  The transposed blocks come from the same code with another record
+//              (Model::closed_form_row<true>), (dxi/dx)^T g from Model::closed_form_adjoint.
+template <class E, template <class> class ModelT, int MAXDEG, bool MANY, bool ADJ = false, class EX>
 C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& sh, MeshTables const& mt, ModelSettings const& ms,
-                            FieldArgs const& fa, GatherArgs const& ga, int node) {
+                            FieldArgs const& fa, GatherArgs const& ga, int node, AdjointArgs const& aa = AdjointArgs{}) {
   using Model = ModelT<Dual>;
   using SH = NodeShared<E, Model, MAXDEG, MANY>;
   using NL_ = NodeLane<MAXDEG>;
@@ -187,6 +192,16 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       int const e = r.e, a = r.a;
       double const* const t = mt.shape + (size_t)e * SHAPE_STRIDE;
       HexShape<E> const Np = HexShape<E>::of_point(pt);
+      // adjoint assembly: this point's history entries (f at the node's four rows, g), fetched under the interpolation
+      double fh4[4] = {0., 0., 0., 0.}, gx[NL];
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) gx[j] = 0.;
+      if constexpr (ADJ) {
+        double const* const fh = aa.f + ((size_t)e * E::NP0 + pt) * E::NDOF;
+        fh4[0] = fh[3 * a + 0]; fh4[1] = fh[3 * a + 1]; fh4[2] = fh[3 * a + 2]; fh4[3] = fh[3 * E::NN + a];
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) gx[j] = aa.g[((size_t)e * E::NP0 + pt) * NL + j];
+      }
       // interpolation (global_residual.cpp:289-332): the same sequential sums over the nodes as interp_ab; four nodes'
       // operands in flight at a time
       double q[WQ];
@@ -219,7 +234,7 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       int const es = mt.elem_set ? mt.elem_set[e] : 0;
       typename Model::ClosedForm cf;
       Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, q, xi_old, ms.abs_tol, t[SHAPE_H], ms.stab_mult, cf, true);
-      if (a == 0) {  // local->scatter (local_residual.cpp:624-631): once per element, by the wavefront of its first node
+      if (!ADJ && a == 0) {  // local->scatter (local_residual.cpp:624-631): once per element, by the wavefront of its first node
         C8_UNROLL
         for (int j = 0; j < NL; ++j) fa.xi[q0 + j] = cf.xi[j];
       }
@@ -229,12 +244,24 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       double const Na = Np.at_node(a);
       double* const rc = sh.rec(s, pt);
       double el[2];
-      Model::closed_form_row(cf.t, w, g, Na, rc, el);
+      Model::template closed_form_row<ADJ>(cf.t, w, g, Na, rc, el);
       if (pt == 0) { sh.el[s][0] = el[0]; sh.el[s][1] = el[1]; }
-      // the point's share of R_(node,.): fluxes contracted with the row node's shape entries
-      C8_UNROLL
-      for (int i = 0; i < 3; ++i) rc[NR + i] = w * (cf.F[3 * i] * g[0] + cf.F[3 * i + 1] * g[1] + cf.F[3 * i + 2] * g[2]);
-      rc[NR + 3] = w * (cf.F[9] * Na + cf.F[10] * g[0] + cf.F[11] * g[1] + cf.F[12] * g[2]);
+      if constexpr (!ADJ) {
+        // the point's share of R_(node,.): fluxes contracted with the row node's shape entries
+        C8_UNROLL
+        for (int i = 0; i < 3; ++i) rc[NR + i] = w * (cf.F[3 * i] * g[0] + cf.F[3 * i + 1] * g[1] + cf.F[3 * i + 2] * g[2]);
+        rc[NR + 3] = w * (cf.F[9] * Na + cf.F[10] * g[0] + cf.F[11] * g[1] + cf.F[12] * g[2]);
+      } else {
+        // the point's share of the adjoint right-hand side at the node's rows (:486-487): [-dJ/dq + (dxi/dq)^T g] dq/dx + f
+        // with dJ/dq = c_avg w / ndims on the displacement itself (avg_disp.cpp:16-33) and (dxi/dq)^T g = Re on grad u
+        double Re[6];
+        Model::closed_form_adjoint(mt.params + (size_t)es * Model::NPARAMS, cf.t, gx, Re);
+        double const dJ = aa.qoi.c_avg * w / aa.qoi.ndims * Na;
+        rc[NR + 0] = Re[0] * g[0] + Re[1] * g[1] + Re[2] * g[2] - dJ + fh4[0];
+        rc[NR + 1] = Re[1] * g[0] + Re[3] * g[1] + Re[4] * g[2] - dJ + fh4[1];
+        rc[NR + 2] = Re[2] * g[0] + Re[4] * g[1] + Re[5] * g[2] - dJ + fh4[2];
+        rc[NR + 3] = fh4[3];
+      }
     });
     ex.sync();
     C8_NSTAMP(1);

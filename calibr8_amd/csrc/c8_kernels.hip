@@ -443,20 +443,35 @@ k_node_rows_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, GatherArgs ga,
   GpuExec<Lane> ex(threadIdx.x, L);
   node_rows_closed<E, ModelT, MAXDEG, MANY>(ex, sh, mt, ms, fa, ga, first + lb);  // nodes [first, first + count)
 }
+// K3 in the same form (objective "average displacement"): the transposed rows and the adjoint right-hand side
+template <class E, template <class> class ModelT, int MAXDEG, bool MANY>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MANY ? 2 : C8_NODE_WAVES, 4)))
+k_node_rows_closed_adjoint(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, GatherArgs ga, int first, int count, int nblocks) {
+  using Lane = NodeLane<MAXDEG>;
+  __shared__ NodeShared<E, ModelT<Dual>, MAXDEG, MANY> sh;
+  int const lb = xcd_block(blockIdx.x, nblocks);
+  if (lb >= nblocks || lb >= count) return;
+  Lane L;
+  GpuExec<Lane> ex(threadIdx.x, L);
+  node_rows_closed<E, ModelT, MAXDEG, MANY, true>(ex, sh, mt, ms, fa, ga, first + lb, aa);
+}
 // max_node_elems <= 8 (every hex8 mesh cut out of a structured one, most others): the lean form; otherwise a node's
 // elements go through the kernel eight at a time
 template <class E, template <class> class ModelT>
-static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms, FieldArgs const& fa, GatherArgs const& ga,
+static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms, FieldArgs const& fa, AdjointArgs const* aa, GatherArgs const& ga,
                                    int first, int count, int max_degree, int max_node_elems, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   int const nblocks = count;
   int const grid = ((nblocks + 7) / 8) * 8;
-  if (max_degree <= 32 && max_node_elems <= 8)
-    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, 32, false>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
-  else if (max_degree <= GATHER_MAX_DEGREE)
-    hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, true>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
-  else
-    return hipErrorInvalidValue;
+  bool const lean = max_degree <= 32 && max_node_elems <= 8;
+  if (max_degree > GATHER_MAX_DEGREE) return hipErrorInvalidValue;
+  if (aa) {  // adjoint assembly
+    if (lean) hipLaunchKernelGGL((k_node_rows_closed_adjoint<E, ModelT, 32, false>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, *aa, ga, first, count, nblocks);
+    else hipLaunchKernelGGL((k_node_rows_closed_adjoint<E, ModelT, GATHER_MAX_DEGREE, true>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, *aa, ga, first, count, nblocks);
+  } else {
+    if (lean) hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, 32, false>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
+    else hipLaunchKernelGGL((k_node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, true>), dim3(grid), dim3(64), 0, stream, mt, ms, fa, ga, first, count, nblocks);
+  }
   return hipGetLastError();
 }
 template <class E, template <class> class ModelT, class = void> struct NodeKernel {

@@ -25,8 +25,9 @@ struct LaunchArgs {
 
 typedef hipError_t (*LaunchFn)(LaunchArgs const&);
 typedef hipError_t (*GatherFn)(GatherArgs const&, int first, int count, int max_degree, hipStream_t);
-typedef hipError_t (*NodeRowsFn)(MeshTables const&, ModelSettings const&, FieldArgs const&, GatherArgs const&, int first, int count,
-                                 int max_degree, int max_node_elems, hipStream_t);
+// aa = null: forward assembly; aa != null: adjoint assembly (objective "average displacement")
+typedef hipError_t (*NodeRowsFn)(MeshTables const&, ModelSettings const&, FieldArgs const&, AdjointArgs const* aa, GatherArgs const&, int first,
+                                 int count, int max_degree, int max_node_elems, hipStream_t);
 
 struct KernelSet {
   LaunchFn forward_jacobian;   // K1, one lane group (NDOF lanes) per element
@@ -44,7 +45,7 @@ struct KernelSet {
   hipError_t (*shape_tables)(MeshTables const&, double* tab, int nelems, hipStream_t);  // cached shape tables of the wave kernels (hex8, else null)
   int shape_stride;            // doubles per element in that table
   GatherFn gather_rows;        // staged assembly: node rows summed from the element-major stage
-  NodeRowsFn node_rows;        // K1, one wavefront per node, no stage (hex8 models with a closed form, else null)
+  NodeRowsFn node_rows;        // K1 and K3, one wavefront per node, no stage (hex8 models with a closed form, else null)
   int stage_stride;            // doubles per element in the stage
   bool adjoint_slot_stages;    // the slot-per-lane K3 can store into the stage (it transposes through LDS first)
   bool can_stage;              // staged (gather) assembly available for this element type

@@ -326,18 +326,45 @@ template <class T, int DIM> struct SmallJ2Dim {
   static constexpr bool HAS_CLOSED_FORM_ROWS = HAS_CLOSED_FORM;
   static constexpr int NROW = 14;
   // r: w g (3) | w b (n g) (3) | a/2 | w N_a | n' (xx xy xz yy yz zz);   el (the same at every point of an element): tau, 1/kappa
+  // TR = true: the record of the TRANSPOSED blocks d R_(m,.) / d x_(a,.) -- what the adjoint assembly scatters
+  // (evaluations.cpp:463-465) --; they differ from the blocks above only in which side carries n' and which n
+  template <bool TR = false>
   C8_HD static void closed_form_row(double const* t, double w, double const* g, double Na, double* r, double* el) {
     double const a = t[0], b = t[1], trn3 = t[2];
     double const* n = t + 5;
     r[0] = w * g[0]; r[1] = w * g[1]; r[2] = w * g[2];
     double const wb = w * b;
+    double const ta = TR ? trn3 : 0., tb = TR ? 0. : trn3;  // n' on the row node's side (TR) or on the column node's
     C8_UNROLL
-    for (int i = 0; i < 3; ++i) r[3 + i] = wb * (n[3 * i] * g[0] + n[3 * i + 1] * g[1] + n[3 * i + 2] * g[2]);
+    for (int i = 0; i < 3; ++i) r[3 + i] = wb * (n[3 * i] * g[0] + n[3 * i + 1] * g[1] + n[3 * i + 2] * g[2] - ta * g[i]);
     r[6] = 0.5 * a;
     r[7] = w * Na;
-    r[8] = n[0] - trn3; r[9] = n[1]; r[10] = n[2]; r[11] = n[4] - trn3; r[12] = n[5]; r[13] = n[8] - trn3;
+    r[8] = n[0] - tb; r[9] = n[1]; r[10] = n[2]; r[11] = n[4] - tb; r[12] = n[5]; r[13] = n[8] - tb;
     el[0] = t[4];
     el[1] = t[3];
+  }
+  // (d xi / d eps)^T gxi at the point, as a symmetric tensor Re (xx xy xz yy yz zz): the term (dxi/dx)^T g of the adjoint
+  // right-hand side (evaluations.cpp:486-487) without the elimination of dC/dxi.  From the radial return
+  //   d pstrain = (2 mu / H) (n' : d eps) n + (1 - theta) (dev d eps - n (n' : d eps)),   d alpha = sqrt(2/3) (2 mu / H) n' : d eps
+  // (elastic points: theta = 1, b = 0, and 2 mu / H below vanishes with them: Re = 0 as dC/dx = 0 gives).
+  C8_HD static void closed_form_adjoint(double const* prm, double const* t, double const* gxi, double* Re) {
+    double const sqrt_23 = 0.81649658092772603273;
+    double const mu = prm[0] * c8_rcp(2. * (1. + prm[1]));
+    double const i2mu = c8_rcp(2. * mu);
+    double const a = t[0], b = t[1], trn3 = t[2];
+    double const* n = t + 5;
+    double const omt = 1. - a * i2mu;     // 1 - theta
+    double const tmH = omt - b * i2mu;    // 2 mu / H
+    double const G[6] = {gxi[0], 0.5 * gxi[1], 0.5 * gxi[2], gxi[3], 0.5 * gxi[4], gxi[5]};  // g . d xi = G : d pstrain
+    double const Gn = G[0] * n[0] + G[3] * n[4] + G[5] * n[8] + 2. * (G[1] * n[1] + G[2] * n[2] + G[4] * n[5]);
+    double const ca = -(b * i2mu) * Gn + gxi[NSYM] * sqrt_23 * tmH;
+    double const trG3 = (G[0] + G[3] + G[5]) * (1. / 3.);
+    Re[0] = ca * (n[0] - trn3) + omt * (G[0] - trG3);
+    Re[1] = ca * n[1] + omt * G[1];
+    Re[2] = ca * n[2] + omt * G[2];
+    Re[3] = ca * (n[4] - trn3) + omt * (G[3] - trG3);
+    Re[4] = ca * n[5] + omt * G[4];
+    Re[5] = ca * (n[8] - trn3) + omt * (G[5] - trG3);
   }
   // J[4 i + k] += block entry (row i of the row node, column k of the column node; 3 = p)
   C8_HD static void closed_form_block(double const* r, double const* el, double const* h, double Nm, double* J) {

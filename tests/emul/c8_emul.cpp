@@ -77,7 +77,7 @@ template <class Lane, int NDOF> struct CpuExec {
   }
 };
 
-enum { K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_ADJ_JAC_NODE = 15, K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 // objective configuration for the next calls (what c8_set_qoi_calibration / c8_set_measured keep in the context)
 struct EmuQoi {
@@ -247,7 +247,10 @@ template <template <class> class ModelT, bool MANY> static void run_node_rows_as
   auto* ex = new CpuExec<NodeLane<GATHER_MAX_DEGREE>, 64>();
   GatherArgs ga{c.mt.nodeptr, c.mt.pos, c.graph->nodeelem_ptr.data(), c.graph->nodeelem.data(), nullptr, 0, nullptr,
                 {{c.sa.A[0][0], c.sa.A[0][1]}, {c.sa.A[1][0], c.sa.A[1][1]}}, {c.sa.b[0], c.sa.b[1]}, c.assign};
-  auto one = [&](int n) { node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, MANY>(*ex, *sh, c.mt, c.ms, c.fa, ga, n); };
+  auto one = [&](int n) {
+    if (c.what == K_ADJ_JAC_NODE) node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, MANY, true>(*ex, *sh, c.mt, c.ms, c.fa, ga, n, c.aa);
+    else node_rows_closed<E, ModelT, GATHER_MAX_DEGREE, MANY>(*ex, *sh, c.mt, c.ms, c.fa, ga, n);
+  };
   int const half = c.staged ? c.nnodes / 2 : 0;
   for (int n = half; n < c.nnodes; ++n) one(n);
   for (int n = 0; n < half; ++n) one(n);
@@ -304,7 +307,7 @@ static int dispatch_2d(std::string const& model, Call const& c) {
 }
 
 template <class E> static int dispatch(std::string const& model, Call const& c) {
-  if (c.what == K_FORWARD_NODE) {
+  if (c.what == K_FORWARD_NODE || c.what == K_ADJ_JAC_NODE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "small_J2") return run_node_rows<SmallJ2>(c);
     return -4;
@@ -423,7 +426,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
     return (elem_type == C8_HEX8) ? dispatch<Elem<C8_HEX8>>(local_type, c) : dispatch<Elem<C8_TET4>>(local_type, c);
   };
   int const base = c.what;
-  bool const is_qoi = base == K_QOI || base == K_QOI_WAVE, is_k3 = base == K_ADJ_JAC || base == K_ADJ_JAC_WAVE,
+  bool const is_qoi = base == K_QOI || base == K_QOI_WAVE, is_k3 = base == K_ADJ_JAC || base == K_ADJ_JAC_WAVE || base == K_ADJ_JAC_NODE,
              is_k5 = base == K_GRAD || base == K_GRAD_WAVE, is_pre = base == K_QOI_PREPROCESS;
   if (g_qoi.kind == 1 && (is_qoi || is_k3 || is_k5 || is_pre)) {
     // the sequence of c8_qoi.hip: tables (set-up), preprocess_qoi, then the entry point with the point integrand

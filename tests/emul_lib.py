@@ -16,7 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE = 11, 12, 13, 14
+K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE, K_ADJ_JAC_NODE = 11, 12, 13, 14, 15
 
 
 def lib():
@@ -104,7 +104,8 @@ class Emul:
         return self._call(K_RESIDUAL_WAVE if self.wave else K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def adjoint_jacobian(self, u, p, up, pp, xip, xi, g, f, ls):
-        what = (K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0) | (512 if self.assign else 0)
+        node = self.node and getattr(self, "_cal", None) is None  # the library: average-displacement objective only
+        what = (K_ADJ_JAC_NODE if node else K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0) | (512 if self.assign else 0)
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls), 12: g, 13: f})
 
     def solve_adjoint_local(self, u, p, up, pp, xip, xi, z_u, z_p, phi, g, f):

@@ -42,6 +42,25 @@ def notched_bar(nx, ny, nz, lx=4.0, ly=1.0, lz=1.0, depth=0.3, halfwidth=0.25):
     return np.ascontiguousarray(coords), np.ascontiguousarray(conn), sets
 
 
+def pinched_bricks():
+    """Two 2 x 2 x 2 hex8 bricks that share exactly one node: the centre node of the first is also the centre node of the
+    second (which is rotated and shrunk so that no other nodes coincide).  That node has sixteen elements and 53 graph
+    neighbours: the case of a node with more than eight elements (unstructured hex8 meshes have them at irregular points)."""
+    c1, conn1, _ = brick(2, 2, 2, 1.0, 1.0, 1.0)
+    c2, conn2, _ = brick(2, 2, 2, 0.8, 0.9, 0.7)
+    ctr1, ctr2 = 13, 13  # centre node of a 3 x 3 x 3 node grid
+    th = 0.6
+    R = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    c2 = (c2 - c2[ctr2]) @ R.T + c1[ctr1]
+    keep = np.arange(len(c2)) != ctr2
+    new_id = np.full(len(c2), -1, dtype=np.int64)
+    new_id[keep] = len(c1) + np.arange(keep.sum())
+    new_id[ctr2] = ctr1
+    coords = np.concatenate([c1, c2[keep]])
+    conn = np.concatenate([conn1, new_id[conn2]]).astype(np.int32)
+    return np.ascontiguousarray(coords), np.ascontiguousarray(conn)
+
+
 def tri_mesh(nx, ny, lx=1.0, ly=1.0):
     """Structured tri3 mesh of a rectangle (each cell split along alternating diagonals), counter-clockwise triangles;
     coords [n][3] with z = 0 (the layout the 2-D path takes)."""

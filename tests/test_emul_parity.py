@@ -74,6 +74,39 @@ def test_forward_jacobian_row_per_node_kernel(model, params, eps, two_part):
     check_forward(orc, dut, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("two_part", [False, True])
+@pytest.mark.parametrize("model,params,eps", CASES[:2])
+def test_adjoint_chain_row_per_node_kernel(model, params, eps, two_part):
+    # K3 in the row-per-node form: transposed blocks from the closed form's tangent, right-hand side -dJ/dx + f +
+    # (dxi/dx)^T g with (dxi/dx)^T g in closed form (no elimination of dC/dxi); K4 and K5 are the wave kernels
+    orc, dut, c = make_pair(factory, "hex8", model, params)
+    dut.node, dut.wave, dut.staged = True, True, two_part
+    check_adjoint_chain(orc, dut, c, model, eps, TOL)
+
+
+@pytest.mark.parametrize("force_many", [False, True])
+def test_row_per_node_kernel_nodes_with_many_elements(force_many):
+    # a node with sixteen elements goes through the kernel eight elements at a time (its second form, with separate
+    # accumulator storage); force_many runs that form on a mesh that does not need it
+    import oracle_lib as ol
+    from meshes import pinched_bricks
+    from parity_cases import mesh_of
+    if force_many:
+        et, c, conn = mesh_of("hex8")
+    else:
+        et = ol.HEX8
+        c, conn = pinched_bricks()
+    orc = ol.Oracle(et, c, conn, "small_J2", CASES[1][1])
+    dut = em.Emul(et, c, conn, "small_J2", CASES[1][1])
+    dut.node = dut.wave = True
+    em.lib().c8emu_set_node_many(1 if force_many else 0)
+    try:
+        check_forward(orc, dut, c, "small_J2", 0.004, TOL)
+        check_adjoint_chain(orc, dut, c, "small_J2", 0.004, TOL)
+    finally:
+        em.lib().c8emu_set_node_many(0)
+
+
 def test_row_per_node_kernel_assign_mode_and_ragged_meshes():
     import oracle_lib as ol
     from meshes import brick, notched_bar, prescribed_fields

@@ -235,6 +235,13 @@ def test_row_per_node_kernel_hex8(model, params, eps):
     check_forward(orc, gpu, c, model, eps, TOL)
 
 
+@pytest.mark.parametrize("model,params,eps", CASES[:2])
+def test_row_per_node_kernel_adjoint_chain_hex8(model, params, eps):
+    # K3 in the row-per-node form (transposed blocks, closed-form (dxi/dx)^T g), then K4 and K5 on its outputs
+    orc, gpu, c = make_pair(factory("gather", "node"), "hex8", model, params)
+    check_adjoint_chain(orc, gpu, c, model, eps, TOL)
+
+
 def test_row_per_node_kernel_ragged_meshes_sets_and_refusals():
     import torch
     from calibr8_amd import Assembler
@@ -248,6 +255,12 @@ def test_row_per_node_kernel_ragged_meshes_sets_and_refusals():
     c, conn, _ = notched_bar(10, 6, 3)  # node degrees 8 .. 27, nodes with 1 .. 8 elements
     orc, gpu = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2), GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather", kernel="node")
     check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
+    check_adjoint_chain(orc, gpu, c, "small_J2", 0.004, TOL)
+    from meshes import pinched_bricks
+    c, conn = pinched_bricks()  # a node with sixteen elements: the kernel's form that takes a node's elements eight at a time
+    orc, gpu = ol.Oracle(ol.HEX8, c, conn, "small_J2", J2), GpuBackend(ol.HEX8, c, conn, "small_J2", J2, scatter="gather", kernel="node")
+    check_forward(orc, gpu, c, "small_J2", 0.004, TOL)
+    check_adjoint_chain(orc, gpu, c, "small_J2", 0.004, TOL)
     # it is what the default takes for this model and element, bit for bit, and two runs agree bit for bit
     c, conn = hex_mesh((5, 4, 3))
     u_h, p_h = prescribed_fields(c, 0.004, ramp=True)

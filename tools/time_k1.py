@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--assign", action="store_true")
     ap.add_argument("--eps", type=float, default=0.004)
+    ap.add_argument("--adjoint", action="store_true", help="time c8_assemble_adjoint_jacobian (K3) instead of the forward assembly")
     a = ap.parse_args()
     import torch
     from calibr8_amd import Assembler
@@ -35,19 +36,24 @@ def main():
     asm.set_async(True)
     if a.assign:
         asm.set_assign_mode(True)
+    asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)  # the converged state of the step
+    g_h = torch.zeros(asm.nelems, asm.npts, asm.nloc, dtype=torch.float64, device=u.device)
+    f_h = torch.zeros(asm.nelems, asm.npts, asm.ndofs, dtype=torch.float64, device=u.device)
+    call = (lambda: asm.adjoint_jacobian(u, p, u0, p0, xi_prev, xi, g_h, f_h, ls)) if a.adjoint else \
+        (lambda: asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls))
     for k in a.kernels.split(","):
         asm.set_kernel(k)
         for _ in range(3):
-            asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+            call()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
         for s, e in ev:
             s.record()
-            asm.forward_jacobian(u, p, u0, p0, xi_prev, xi, ls)
+            call()
             e.record()
         torch.cuda.synchronize()
         assert asm.status() == 0
         t = np.array([s.elapsed_time(e) for s, e in ev])
-        print("%-14s %-8s median %.3f ms  min %.3f  max %.3f   (%.1f M elements/s)" % (a.tag, k, np.median(t), t.min(), t.max(), len(conn) / np.median(t) / 1e3), flush=True)
+        print("%-14s %-8s %s median %.3f ms  min %.3f  max %.3f   (%.1f M elements/s)" % (a.tag, k, "K3" if a.adjoint else "K1", np.median(t), t.min(), t.max(), len(conn) / np.median(t) / 1e3), flush=True)
 
 
 if __name__ == "__main__":
