@@ -394,6 +394,10 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
 // ADJOINT = true : eval_adjoint_jacobian (evaluations.cpp:349-526): no local solve (stored xi), the element
 //                  matrix is scattered transposed, and the right-hand side is -dJ/dx + f + (dxi/dx)^T g with
 //                  g -= dJ/dxi updated in place; every x-derivative goes through the point quantities q.
+template <class M, bool ADJ, class = void> struct pin_phases : std::false_type {};
+template <class M> struct pin_phases<M, false, std::enable_if_t<M::PIN_PHASES_K1>> : std::true_type {};
+template <class M> struct pin_phases<M, true, std::enable_if_t<M::PIN_PHASES_K3>> : std::true_type {};
+
 template <class E, template <class> class ModelT, class QoI, bool ADJOINT, bool CLOSED = false, class EX, class SH>
 C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings const& ms,
                          FieldArgs const& fa, AdjointArgs const& aa, SystemArgs const& sa, int e) {
@@ -402,10 +406,15 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   constexpr bool PREV = Model::FINITE_DEF;
   static_assert(E::NDOF == 32 && E::NP0 == 8 && E::SAME_POINTS, "wave kernel needs a hex8-like element");
   static_assert(NL <= 8, "at most 8 local unknowns per point");
+  // lane-derived values (DOF slots, seeds, table offsets) formed in the phase that uses them instead of at the top of the
+  // kernel (C8_PIN on the lane number at the head of every phase): a register-allocation switch per model and kernel, as
+  // measured (hyper_J2 K1 23.5 -> 21.5 ms, K3 16.1 -> 13.9; hypo_hill 30.9 -> 29.8, 32.6 -> 29.2; small_hill K3 12.7 -> 11.3;
+  // small_J2 and small_hill K1 lose 3-7 % with it)
+  constexpr bool PIN = pin_phases<Model, ADJOINT>::value;
 
   C8_STAMP(0);
   // ---- load: lanes 0..31 = element DOF slots; shape tables: lane = point*8 + node ----------
-  ex.each([&](int lane) {
+  ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
     auto& r = ex.lane(lane);
     r.failed = false;
     r.R = 0.;
@@ -448,7 +457,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   ex.sync();
   C8_STAMP(10);
   if (!mt.shape) {
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       shape_entry<E>(sh, 0, lane >> 3, lane & 7, (lane & 7) + 1);
       if (lane == 0) sh.h = elem_size<E>(sh);
     });
@@ -456,7 +465,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   }
   C8_STAMP(11);
   // ---- interpolation: lane (pt, d) computes quantities 2d and 2d+1 (and grad_u_prev) --------------
-  ex.each([&](int lane) {
+  ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
     int const pt = lane >> 3, d = lane & 7;
     {
       int const k0 = 2 * d, k1 = 2 * d + 1;  // products (a, b) = (k >> 2, k & 3)
@@ -487,7 +496,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   bool need_inverse = false;
   if constexpr (!CLOSED) {  // CLOSED: the model's closed form replaces phases N, the inverse and the AD passes of phase D
   // ---- phase N: local Newton at all 8 points (small_J2.cpp:122-173) ---------------------------
-  ex.each([&](int lane) {
+  ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
     auto& r = ex.lane(lane);
     int const pt = lane >> 3, d = lane & 7;
     load_params(r.m, mt, e);
@@ -522,9 +531,9 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   });
   if (Model::HAS_LOCAL && !ADJOINT) {
     auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
-    ex.each([&](int lane) { auto& r = ex.lane(lane); r.trial = r.m.trial(r.g); });  // once per point, not per iteration
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = r.m.trial(r.g); });  // once per point, not per iteration
     while (ex.any(running)) {
-      ex.each([&](int lane) {
+      ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
         auto& r = ex.lane(lane);
         if (!running(lane)) return;
         int const pt = lane >> 3, d = lane & 7;
@@ -552,7 +561,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
                                      [&](int lane) { return ex.lane(lane).b; }, running);
       else
         ok = local_solve<NL, C8_XL_NEWTON(Model)>(ex, sh, running);
-      ex.each([&](int lane) {
+      ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
         auto& r = ex.lane(lane);
         if (!running(lane)) return;
         if (!ok) { r.failed = true; r.iter = ms.max_iters + 1; return; }
@@ -562,7 +571,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       });
     }
   }
-  ex.each([&](int lane) {
+  ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
     auto& r = ex.lane(lane);
     int const pt = lane >> 3, d = lane & 7;
     if ((r.iter > ms.max_iters) && !r.converged) r.failed = true;
@@ -590,7 +599,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       return notI;
     });
     if (need_inverse) {
-      ex.each([&](int lane) {
+      ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
         auto& r = ex.lane(lane);
         int const d = lane & 7;
         int const pt = lane >> 3;
@@ -601,7 +610,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
         }
       });
       bool const ok = local_solve<NL, C8_XL_INVERSE(Model)>(ex, sh, [](int) { return true; });
-      ex.each([&](int lane) {
+      ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
         auto& r = ex.lane(lane);
         int const pt = lane >> 3, d = lane & 7;
         if (d < NL) {
@@ -620,7 +629,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     // point quantities and the previous state, stores the converged state and the weighted fluxes, and leaves what the
     // tangent columns need IN PLACE OF the point quantities (sh.q[pt][0 .. NT-1]; nothing reads q afterwards)
     static_assert(Model::ClosedForm::NT <= WQ, "the tangent data take the place of the point quantities");
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       int const pt = lane >> 3, d = lane & 7;
       if (d != 0) return;
       int const es = mt.elem_set ? mt.elem_set[e] : 0;
@@ -647,7 +656,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     //      once per point for 13 products.  J holds the rows (n, u_0), (n, u_1) (flux group 0), J1 the rows (n, u_2),
     //      (n, p) (group 1), in the order the scatter expects; the halves exchange their partial sums below.
     static_assert(!ADJOINT && !Mechanics::USES_U, "the closed-form kernel is the forward assembly of a weak form without u terms");
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       auto& r = ex.lane(lane);
       int const b = lane & 31, hf = lane >> 5;
       bool const bu = b < 3 * E::NN;
@@ -691,7 +700,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   } else
   // ---- phases D and P, 4 points per pass -------------------------------------------------------------
   for (int t = 0; t < 2; ++t) {
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       auto& r = ex.lane(lane);
       int const ql = lane >> 4, c = lane & 15, pt = 4 * t + ql;
       load_params(r.m, mt, e);
@@ -760,7 +769,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     //   g = 1: entries (node n, u_2) from flux rows 6..8 and (n, p)   from flux rows 9..12
     // Both halves run one instruction stream: entry E0 takes rows r0..r0+2, entry E1 rows r1..r1+2 plus
     // row 9 with weight zf (zero for g = 0).  J[2n] = E0 of node n, J[2n+1] = E1 of node n.
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       auto& r = ex.lane(lane);
       int const b = lane & 31, g = lane >> 5;
       bool const bu = b < 3 * E::NN;
@@ -832,7 +841,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     // the halves exchange their partial sums: half 0 completes group 0 (its J and the other half's J), half 1 group 1 (the
     // other half's J1 and its own), both into J, which the scatter reads.  One lane-pair exchange per accumulator
     // (EX::pair_sum32: v_permlane32_swap on the device, no LDS traffic and no selects)
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       auto& r = ex.lane(lane);
       C8_UNROLL
       for (int k = 0; k < 16; ++k)
@@ -840,7 +849,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       double const Rr = ex.xor32(lane, [&](int l) { return ex.lane(l).R; });
       r.Rx = Rr;
     });
-    ex.each([&](int lane) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
       auto& r = ex.lane(lane);
       r.R += r.Rx;
     });
@@ -850,7 +859,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
   C8_STAMP(8);
   // ---- scatter: lane (g, b) holds column b of the rows (n, u_2g) [J[2n]] and (n, u_1) or (n, p) [J[2n+1]];
   //      the adjoint assembly stores them transposed (evaluations.cpp:463-465) ------------------------------
-  ex.each([&](int lane) {
+  ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
     auto& r = ex.lane(lane);
     int const b = lane & 31, g = lane >> 5;
     int ib, nb, eqb;

@@ -550,6 +550,7 @@ template <class T> struct HyperJ2PlaneStrain {
 
 // ---- small_hill.cpp (Hill's anisotropic yield function, yield_functions.hpp:34-99; Voce hardening) ---------
 template <class T> struct SmallHill {
+  static constexpr bool PIN_PHASES_K1 = false, PIN_PHASES_K3 = true;  // jacobian_wave: lane-derived values per phase (pin_phases), as measured
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
@@ -623,6 +624,7 @@ template <class T> struct SmallHill {
 // ---- hypo_hill.cpp: hypoelastic rate form in the unrotated configuration (local unknown = unrotated Cauchy stress
 //      TC), Hill's yield function (yield_functions.hpp:34-99), Voce hardening --------------------------------------
 template <class T> struct HypoHill {
+  static constexpr bool PIN_PHASES_K1 = true, PIN_PHASES_K3 = true;  // jacobian_wave: lane-derived values per phase (pin_phases), as measured
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
@@ -1352,6 +1354,7 @@ template <class T> struct HypoBarlat : HypoPrincipalBase<T, HypoBarlat<T>, 25> {
 
 // ---- hyper_J2.cpp -------------------------------------------------------------
 template <class T> struct HyperJ2 {
+  static constexpr bool PIN_PHASES_K1 = true, PIN_PHASES_K3 = true;  // jacobian_wave: lane-derived values per phase (pin_phases), as measured
   static constexpr int NLOC = 8, NPARAMS = 8;
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
   // measured on 1 M hex8 elements: at 256 registers the local-adjoint kernel spills 1 KB per lane (32 ms), at 512

@@ -429,10 +429,13 @@ def test_closed_form_against_iterated_form(params):
         return [xi1, xi2] + [l.b[i] for l in (l1, l2) for i in range(2)] + \
                [l.A[i][j] for l in (l1, l2) for i in range(2) for j in range(2)]
 
-    closed, iterated, again = run("auto"), run("wave_ad"), run("wave")
-    for a, b, a2 in zip(closed, iterated, again):
+    # "auto" = the row-per-node kernel (closed form), "wave" = the staged one-wavefront-per-element kernel (closed form),
+    # "wave_ad" = the latter with the iterated, automatically differentiated local solve
+    closed, iterated, again, staged = run("auto"), run("wave_ad"), run("auto"), run("wave")
+    for a, b, a2, a3 in zip(closed, iterated, again, staged):
         assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
-        assert np.array_equal(a, a2)  # staged assembly: bitwise reproducible, and "wave" is the default form again
+        assert np.array_equal(a, a2)  # bitwise reproducible, also after a switch of the kernel variant and back
+        assert np.abs(a - a3).max() <= 1e-13 * np.abs(a3).max()  # the two closed-form kernels: the same sums in another order
 
 
 @pytest.mark.parametrize("scatter", ["gather", "atomic"])

@@ -17,9 +17,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--edge", type=int, default=100)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--scatter", default="atomic")
-    ap.add_argument("--model", default="small_J2", choices=["small_J2", "hyper_J2", "small_hill", "elastic", "hypo_hill"])
+    ap.add_argument("--scatter", default="atomic", help="atomic | colored | gather | default (the library's choice per entry point)")
+    ap.add_argument("--model", default="small_J2", choices=["small_J2", "hyper_J2", "small_hill", "elastic", "hypo_hill", "small_hosford", "hypo_hosford",
+                                                            "hypo_barlat", "small_hill_plane_strain", "hyper_J2_plane_strain", "hypo_hill_plane_strain",
+                                                            "small_hill_plane_stress", "hyper_J2_plane_stress", "hypo_hill_plane_stress"])
     ap.add_argument("--tet", action="store_true", help="split every hex into 6 tet4 (the reference's element type)")
+    ap.add_argument("--tri", action="store_true", help="a tri3 mesh of 2 * (7 * edge)^2 elements (the reference's 2-D element type; 2-D models)")
     args = ap.parse_args()
     import torch
     from calibr8_amd import Assembler, brick_mesh
@@ -35,12 +38,23 @@ def main():
         vol = np.einsum("ij,ij->i", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 3] - X[:, 0])
         assert (vol > 0).all()
         et = 4
-    from parity_cases import ACTIVE, EL, HILL, HJ2
-    params = {"small_J2": J2, "hyper_J2": HJ2, "small_hill": HILL, "elastic": EL, "hypo_hill": HILL}[args.model]
-    asm = Assembler(et, coords, conn, args.model, params, scatter=args.scatter)
+    from parity_cases import ACTIVE, BARLAT, EL, HILL, HILL_PS, HJ2, HJ2_PS, HJ2_PSS, HOSFORD, HYPO_PSS, LOCAL_LINE_SEARCH
+    if args.tri:
+        from meshes import tri_mesh
+        coords, conn, _ = tri_mesh(7 * n, 7 * n, 1.0, 1.0)
+        et = 3
+    params = {"small_J2": J2, "hyper_J2": HJ2, "small_hill": HILL, "elastic": EL, "hypo_hill": HILL, "small_hosford": HOSFORD, "hypo_hosford": HOSFORD,
+              "hypo_barlat": BARLAT, "small_hill_plane_strain": HILL_PS, "hyper_J2_plane_strain": HJ2_PS, "hypo_hill_plane_strain": HILL_PS,
+              "small_hill_plane_stress": HILL_PS, "hyper_J2_plane_stress": HJ2_PSS, "hypo_hill_plane_stress": HYPO_PSS}[args.model]
+    line_search = args.model in ("small_hosford", "hypo_hosford", "hypo_barlat")
+    asm = Assembler(et, coords, conn, args.model, params, scatter=None if args.scatter == "default" else args.scatter,
+                    **({"line_search": LOCAL_LINE_SEARCH} if line_search else {}))
     asm.set_active(0, ACTIVE[args.model][:4])
     asm.set_async(True)
-    u_h, p_h = prescribed_fields(coords, 0.004, ramp=True)
+    u_h, p_h = prescribed_fields(coords, 0.006 if args.model == "hypo_barlat" else 0.004, ramp=True)
+    if args.tri:
+        from meshes import fields_for
+        u_h, p_h = fields_for(2, u_h, p_h)
     u, p = asm.dev(u_h), asm.dev(p_h)
     u0, p0 = torch.zeros_like(u), torch.zeros_like(p)
     xi0, xi = asm.new_state(), asm.new_state()
@@ -66,7 +80,9 @@ def main():
 
     res = {}
     # staged (gather) mode: the hex8 lane-group adjoint kernel cannot stage, time the wave-per-element kernels only
-    variants = ("slot",) if args.tet else (("wave",) if args.scatter == "gather" else ("wave", "slot"))
+    variants = ("slot",) if (args.tet or args.tri or line_search) else (("wave",) if args.scatter == "gather" else ("wave", "slot"))
+    if line_search and not args.tet and args.scatter in ("gather", "default"):
+        variants = ("auto",)  # hex8: the default mode stages K1 and runs K3 in colour batches (no explicit lane-group K3 in this mode)
     for k in variants:
         asm.set_kernel(k)
         res["forward_jacobian_" + k] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))
@@ -82,7 +98,7 @@ def main():
     asm.set_kernel("auto")
     res["residual"] = timeit(lambda: asm.global_residual(u, p, u0, p0, xi0, xi, ls))
     res["eval_qoi"] = timeit(lambda: asm.eval_qoi(u, p, J))
-    out = {"elements": asm.nelems, "element_type": "tet4" if args.tet else "hex8", "model": args.model, "scatter": args.scatter,
+    out = {"elements": asm.nelems, "element_type": "tri3" if args.tri else ("tet4" if args.tet else "hex8"), "model": args.model, "scatter": args.scatter,
            "ms": res, "Melem_per_s": {k: asm.nelems / v / 1e3 for k, v in res.items()}}
     print(json.dumps(out))
 
