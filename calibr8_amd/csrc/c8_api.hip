@@ -338,6 +338,8 @@ int c8_gather_finish(c8_ctx* c) {
     AdjointArgs const* const paa = c->pending_adjoint ? &c->pending_aa : nullptr;
     C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, paa, c->pending_ga, 0, c->early_begin, c->graph.max_degree, c->graph.max_node_elems, c->stream));
     C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, paa, c->pending_ga, c->early_end, c->mesh.nnodes - c->early_end, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+    if (paa && paa->qoi.c_load != 0.)
+      C8_HIP(c->ks.node_rows(mt, c->ms, c->pending_fa, paa, c->pending_ga, -1, c->mesh.nelems, c->graph.max_degree, c->graph.max_node_elems, c->stream));
     return C8_OK;
   }
   int const total = (int)c->plan.node_order.size();
@@ -445,6 +447,8 @@ static int run_node_rows(c8_ctx* c, FieldArgs const& fa, SystemArgs const& sa, A
     return C8_OK;  // the closed form has no failing local solve: nothing to read back
   }
   C8_HIP(c->ks.node_rows(mt, c->ms, fa, aa, ga, 0, c->mesh.nnodes, c->graph.max_degree, c->graph.max_node_elems, c->stream));
+  if (aa && aa->qoi.c_load != 0.)  // calibration objective: g -= dJ/dxi once every wavefront has read the old g
+    C8_HIP(c->ks.node_rows(mt, c->ms, fa, aa, ga, -1, c->mesh.nelems, c->graph.max_degree, c->graph.max_node_elems, c->stream));
   return C8_OK;
 }
 
@@ -536,9 +540,8 @@ static int run(c8_ctx* c, LaunchFn fn, FieldArgs const& fa, AdjointArgs const& a
   if (c->kernel_variant == C8_KERNEL_NODE && fn == c->ks.forward_jacobian_wave && !(staged && node_rows_applies(c, fa)))
     return fail(C8_ERR_UNSUPPORTED, std::string(what) + ": C8_KERNEL_NODE needs C8_SCATTER_GATHER, the shape-table cache and distinct xi / xi_prev arrays");
   if (staged && fn == c->ks.forward_jacobian_wave && node_rows_applies(c, fa)) return run_node_rows(c, fa, sa);
-  // the adjoint assembly in the same form, for the objective whose point integrand has a closed derivative (average
-  // displacement); the calibration objective keeps the dual-number kernel
-  if (staged && fn == c->ks.adjoint_jacobian_wave && node_rows_applies(c, fa) && c->qoi_kind == 0) return run_node_rows(c, fa, sa, &aa);
+  // the adjoint assembly in the same form (both objectives: the point integrands have closed derivatives)
+  if (staged && fn == c->ks.adjoint_jacobian_wave && node_rows_applies(c, fa)) return run_node_rows(c, fa, sa, &aa);
   if (staged) {
     int const rc = run_staged(c, fn, fa, aa, sa);
     if (rc == C8_ERR_DEVICE && c->scatter_auto && !c->d_stage && !c->assign_mode && c->early_end <= c->early_begin) {

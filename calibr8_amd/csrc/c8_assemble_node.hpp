@@ -255,12 +255,22 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
         // the point's share of the adjoint right-hand side at the node's rows (:486-487): [-dJ/dq + (dxi/dq)^T g] dq/dx + f
         // with dJ/dq = c_avg w / ndims on the displacement itself (avg_disp.cpp:16-33) and (dxi/dq)^T g = Re on grad u
         double Re[6];
+        double dq[10];  // dJ/dq of the objective's load term at fixed xi (grad u 0..8, p 9); zero for "average displacement"
+        C8_UNROLL
+        for (int k = 0; k < 10; ++k) dq[k] = 0.;
+        if (aa.qoi.c_load != 0.) {  // calibration objective (uniform over the launch): g -= dJ/dxi first (:474-481); the
+          double dxi[NL];           // updated g is stored by node_rows_update_g once every wavefront has read the old one
+          Model::closed_form_load_term(mt.params + (size_t)es * Model::NPARAMS, aa.qoi.c_load * w, aa.qoi.comp,
+                                       aa.qoi.S + ((size_t)e * E::NP0 + pt) * 3, dxi, dq);
+          C8_UNROLL
+          for (int j = 0; j < NL; ++j) gx[j] -= dxi[j];
+        }
         Model::closed_form_adjoint(mt.params + (size_t)es * Model::NPARAMS, cf.t, gx, Re);
         double const dJ = aa.qoi.c_avg * w / aa.qoi.ndims * Na;
-        rc[NR + 0] = Re[0] * g[0] + Re[1] * g[1] + Re[2] * g[2] - dJ + fh4[0];
-        rc[NR + 1] = Re[1] * g[0] + Re[3] * g[1] + Re[4] * g[2] - dJ + fh4[1];
-        rc[NR + 2] = Re[2] * g[0] + Re[4] * g[1] + Re[5] * g[2] - dJ + fh4[2];
-        rc[NR + 3] = fh4[3];
+        rc[NR + 0] = (Re[0] - dq[0]) * g[0] + (Re[1] - dq[1]) * g[1] + (Re[2] - dq[2]) * g[2] - dJ + fh4[0];
+        rc[NR + 1] = (Re[1] - dq[3]) * g[0] + (Re[3] - dq[4]) * g[1] + (Re[4] - dq[5]) * g[2] - dJ + fh4[1];
+        rc[NR + 2] = (Re[2] - dq[6]) * g[0] + (Re[4] - dq[7]) * g[1] + (Re[5] - dq[8]) * g[2] - dJ + fh4[2];
+        rc[NR + 3] = -dq[9] * Na + fh4[3];
       }
     });
     ex.sync();
@@ -395,6 +405,21 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
   });
   ex.sync();
   C8_NSTAMP(5);
+}
+
+// The adjoint assembly's update of the local history, g -= dJ/dxi (evaluations.cpp:474-481), for the objective's load term:
+// one lane per (element, point), run AFTER the row-per-node launches of the call (every wavefront reads the old g of its
+// elements' points; eight wavefronts read each).  The shape-table weight and the model's derivative are those of phase A.
+template <class E, template <class> class ModelT>
+C8_HD void node_rows_update_g(MeshTables const& mt, AdjointArgs const& aa, size_t qp) {
+  using Model = ModelT<Dual>;
+  int const e = (int)(qp / E::NP0), pt = (int)(qp % E::NP0);
+  int const es = mt.elem_set ? mt.elem_set[e] : 0;
+  double const w = mt.shape[(size_t)e * SHAPE_STRIDE + SHAPE_WDV + pt];
+  double dxi[Model::NLOC], dq[10];
+  Model::closed_form_load_term(mt.params + (size_t)es * Model::NPARAMS, aa.qoi.c_load * w, aa.qoi.comp, aa.qoi.S + qp * 3, dxi, dq);
+  C8_UNROLL
+  for (int j = 0; j < Model::NLOC; ++j) aa.g[qp * Model::NLOC + j] -= dxi[j];
 }
 
 }  // namespace c8

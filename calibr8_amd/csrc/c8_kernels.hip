@@ -463,9 +463,20 @@ k_node_rows_closed_adjoint(MeshTables mt, ModelSettings ms, FieldArgs fa, Adjoin
 // max_node_elems <= 8 (every hex8 mesh cut out of a structured one, most others): the lean form; otherwise a node's
 // elements go through the kernel eight at a time
 template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(256) k_node_rows_update_g(MeshTables mt, AdjointArgs aa, size_t npoints) {
+  size_t const qp = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (qp < npoints) node_rows_update_g<E, ModelT>(mt, aa, qp);
+}
+// first = -1: the update of g that closes an adjoint assembly under the calibration objective (count = elements)
+template <class E, template <class> class ModelT>
 static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms, FieldArgs const& fa, AdjointArgs const* aa, GatherArgs const& ga,
                                    int first, int count, int max_degree, int max_node_elems, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
+  if (first < 0) {
+    size_t const npoints = (size_t)count * E::NP0;
+    hipLaunchKernelGGL((k_node_rows_update_g<E, ModelT>), dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, stream, mt, *aa, npoints);
+    return hipGetLastError();
+  }
   int const nblocks = count;
   int const grid = stripe_grid(nblocks, NODE_STRIPE);
   bool const lean = max_degree <= 32 && max_node_elems <= 8;

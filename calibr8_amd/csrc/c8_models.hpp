@@ -343,6 +343,29 @@ template <class T, int DIM> struct SmallJ2Dim {
     el[0] = t[4];
     el[1] = t[3];
   }
+  // The load term of the calibration objective (calibration.cpp:302-343 re-enters the weak form): J += wc sum_j sigma_(c j) S_j
+  // with sigma = 2 mu (dev eps - pstrain) - p I.  Its partial derivatives at the point: dJ_dxi (local unknowns, packed
+  // symmetric entries (c, j) of pstrain) and dJ_dq (grad u row-major 0..8, p 9) -- what the dual-number kernels obtain by
+  // seeding xi and x in turn (evaluations.cpp:469-481).  c is a run-time index: selected by comparisons, no indexed tables.
+  C8_HD static void closed_form_load_term(double const* prm, double wc, int c, double const* S, double* dJ_dxi, double* dJ_dq) {
+    double const mu2 = prm[0] * c8_rcp(1. + prm[1]);  // 2 mu
+    double const Sc = c == 0 ? S[0] : (c == 1 ? S[1] : S[2]);
+    double const k = wc * mu2;
+    // packed (00, 01, 02, 11, 12, 22): entry (i, j) takes S_j when c == i and, off the diagonal, S_i when c == j
+    dJ_dxi[0] = -k * (c == 0 ? S[0] : 0.);
+    dJ_dxi[1] = -k * (c == 0 ? S[1] : (c == 1 ? S[0] : 0.));
+    dJ_dxi[2] = -k * (c == 0 ? S[2] : (c == 2 ? S[0] : 0.));
+    dJ_dxi[3] = -k * (c == 1 ? S[1] : 0.);
+    dJ_dxi[4] = -k * (c == 1 ? S[2] : (c == 2 ? S[1] : 0.));
+    dJ_dxi[5] = -k * (c == 2 ? S[2] : 0.);
+    dJ_dxi[NSYM] = 0.;
+    C8_UNROLL
+    for (int a = 0; a < 3; ++a)
+      C8_UNROLL
+      for (int l = 0; l < 3; ++l)
+        dJ_dq[3 * a + l] = k * (0.5 * ((c == a ? S[l] : 0.) + (c == l ? S[a] : 0.)) - (a == l ? Sc * (1. / 3.) : 0.));
+    dJ_dq[9] = -wc * Sc;
+  }
   // (d xi / d eps)^T gxi at the point, as a symmetric tensor Re (xx xy xz yy yz zz): the term (dxi/dx)^T g of the adjoint
   // right-hand side (evaluations.cpp:486-487) without the elimination of dC/dxi.  From the radial return
   //   d pstrain = (2 mu / H) (n' : d eps) n + (1 - theta) (dev d eps - n (n' : d eps)),   d alpha = sqrt(2/3) (2 mu / H) n' : d eps

@@ -254,6 +254,8 @@ template <template <class> class ModelT, bool MANY> static void run_node_rows_as
   int const half = c.staged ? c.nnodes / 2 : 0;
   for (int n = half; n < c.nnodes; ++n) one(n);
   for (int n = 0; n < half; ++n) one(n);
+  if (c.what == K_ADJ_JAC_NODE && c.aa.qoi.c_load != 0.)  // the library's closing launch: g -= dJ/dxi (launch_node_rows, first = -1)
+    for (size_t qp = 0; qp < (size_t)c.nelems * E::NP0; ++qp) node_rows_update_g<E, ModelT>(c.mt, c.aa, qp);
   delete ex;
   delete sh;
 }

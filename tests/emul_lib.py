@@ -104,8 +104,7 @@ class Emul:
         return self._call(K_RESIDUAL_WAVE if self.wave else K_RESIDUAL, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls)})
 
     def adjoint_jacobian(self, u, p, up, pp, xip, xi, g, f, ls):
-        node = self.node and getattr(self, "_cal", None) is None  # the library: average-displacement objective only
-        what = (K_ADJ_JAC_NODE if node else K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0) | (512 if self.assign else 0)
+        what = (K_ADJ_JAC_NODE if self.node else K_ADJ_JAC_WAVE if self.wave else K_ADJ_JAC) | (256 if self.staged else 0) | (512 if self.assign else 0)
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls), 12: g, 13: f})
 
     def solve_adjoint_local(self, u, p, up, pp, xip, xi, z_u, z_p, phi, g, f):

@@ -107,6 +107,30 @@ def test_row_per_node_kernel_nodes_with_many_elements(force_many):
         em.lib().c8emu_set_node_many(0)
 
 
+def test_adjoint_row_per_node_kernel_against_iterated_form():
+    # K3 of small_J2 in its two forms on the same stored states (second load step, plastic history, non-zero g): the
+    # row-per-node kernel (closed-form tangent and (dxi/dx)^T g) against the wave kernel (dual numbers, elimination of dC/dxi)
+    import oracle_lib as ol
+    from parity_cases import J2, mesh_of, two_steps
+    et, c, conn = mesh_of("hex8")
+    orc = ol.Oracle(et, c, conn, "small_J2", J2)
+    st = two_steps(orc, c, 0.004)
+    (u, p, xi), (up, pp, xip) = st[2], st[1]
+    rng = np.random.default_rng(3)
+    g0 = 1e-3 * rng.standard_normal((orc.nelems, orc.npts, orc.nloc))
+    f0 = 1e-3 * rng.standard_normal((orc.nelems, orc.npts, 4 * orc.nn))
+    out = []
+    for node in (True, False):
+        dut = em.Emul(et, c, conn, "small_J2", J2)
+        dut.wave, dut.node = True, node
+        ls, g = dut.new_linsys(), g0.copy()
+        assert dut.adjoint_jacobian(u, p, up, pp, xip, xi, g, f0, ls) == 0
+        out.append([g] + ls.b + [ls.A[i][j] for i in range(2) for j in range(2)])
+    for a, b in zip(*out):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    assert np.array_equal(out[0][0], g0)  # the average-displacement objective leaves g as it is
+
+
 def test_row_per_node_kernel_assign_mode_and_ragged_meshes():
     import oracle_lib as ol
     from meshes import brick, notched_bar, prescribed_fields
@@ -256,7 +280,7 @@ def test_tiny_and_ragged_meshes():
     check_tiny_and_ragged(factory, TOL)
 
 
-@pytest.mark.parametrize("kind,wave", [("hex8", True), ("hex8", False), ("tet4", False)])
+@pytest.mark.parametrize("kind,wave", [("hex8", True), ("hex8", "node"), ("hex8", False), ("tet4", False)])
 def test_calibration_objective(kind, wave):
     # Calibration QoI (calibration.cpp) through the kernel source on the CPU: set-up tables, preprocess (total load),
     # value, and the x / xi / parameter derivatives through K3 -> K4 -> K5, against the oracle
@@ -274,7 +298,8 @@ def test_calibration_objective(kind, wave):
     kw = dict(weights=(1.0, 2.0, 0.5), balance=0.3, coord_idx=1, coord_value=float(ymin), coord_tol=0.06, comp=1, dt_over_T=0.5)
     orc = ol.Oracle(et, c, conn, "small_J2", J2)
     dut = factory(et, c, conn, "small_J2", J2)
-    dut.wave = wave
+    dut.wave = bool(wave)
+    dut.node = wave == "node"  # K3 in the row-per-node form: the load term's derivatives in closed form, g updated afterwards
     orc.set_calibration(faces, **kw)
     dut.set_calibration(faces, **kw)
     st = two_steps(orc, c, 0.004)

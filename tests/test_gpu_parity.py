@@ -242,6 +242,34 @@ def test_row_per_node_kernel_adjoint_chain_hex8(model, params, eps):
     check_adjoint_chain(orc, gpu, c, model, eps, TOL)
 
 
+def test_adjoint_row_per_node_kernel_against_iterated_form():
+    # K3 of small_J2 on a 12^3 brick in its two forms on the same stored states (plastic history, non-zero g and f): the
+    # row-per-node kernel (closed form) against the staged wave kernel (dual numbers); bitwise reproducible
+    import torch
+    from calibr8_amd import Assembler
+    c, conn = hex_mesh((12, 12, 12))
+    u_h, p_h = prescribed_fields(c, 0.004, ramp=True, perturb=5e-2)
+    res = []
+    for kernel in ("node", "wave", "node"):
+        asm = Assembler(8, c, conn, "small_J2", J2, scatter="gather")
+        asm.set_kernel(kernel)
+        u1, p1 = asm.dev(u_h), asm.dev(p_h)
+        z, zp = torch.zeros_like(u1), torch.zeros_like(p1)
+        xi0, xi1, xi2 = asm.new_state(), asm.new_state(), asm.new_state()
+        assert asm.forward_jacobian(u1, p1, z, zp, xi0, xi1, asm.new_linsys()) == 0
+        assert asm.forward_jacobian(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, asm.new_linsys()) == 0
+        gen = torch.Generator(device="cpu").manual_seed(5)
+        g = (1e-3 * torch.randn(asm.nelems, asm.npts, asm.nloc, generator=gen, dtype=torch.float64)).to(asm.device)
+        f = (1e-3 * torch.randn(asm.nelems, asm.npts, asm.ndofs, generator=gen, dtype=torch.float64)).to(asm.device)
+        g_in = g.clone()
+        ls = asm.new_linsys()
+        assert asm.adjoint_jacobian(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, g, f, ls) == 0
+        assert torch.equal(g, g_in)  # average displacement: dJ/dxi = 0
+        res.append(ls.flat.clone())
+    assert torch.equal(res[0], res[2])
+    assert float((res[0] - res[1]).abs().max() / res[1].abs().max()) < 1e-12
+
+
 def test_row_per_node_kernel_ragged_meshes_sets_and_refusals():
     import torch
     from calibr8_amd import Assembler
