@@ -13,7 +13,7 @@ timeout -k 10 900 python3 tools/collect_pmc.py --out $O/pmc_gather.json -- --sca
 echo pmc done
 # the bench line takes roofline.traffic / roofline.valu from a PMC profile of THIS build under profiles/: put the one just
 # collected there (on the box; tools/save_profiles.py does the same in the repository) before the bench runs
-if [ -n "$2" ]; then cp $O/pmc_gather.json profiles/$2_traffic_wave_gather_100cube.json; fi
+if [ -n "$2" ]; then cp $O/pmc_gather.json profiles/$2_traffic_gather_100cube.json; fi
 timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo bench default done
 timeout -k 10 200 python3 bench.py --no-cpu --scatter atomic > $O/bench_atomic.json 2>/dev/null || exit 1
@@ -25,6 +25,8 @@ timeout -k 10 300 python3 tools/bench_kernels.py --model hyper_J2 > $O/kernels_h
 timeout -k 10 300 python3 tools/bench_kernels.py --model small_hill > $O/kernels_small_hill.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --model hypo_hill > $O/kernels_hypo_hill.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_kernels.py --tet --edge 56 --scatter gather > $O/kernels_tet4_gather.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/time_k1.py --kernels auto,wave,wave_ad > $O/k1_kernels.log 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/time_k1.py --kernels auto,wave --adjoint > $O/k3_kernels.log 2>/dev/null || exit 1
 # the same in the library's default mode (staged assembly + row sums) for the four hex8 models
 for m in small_J2 hyper_J2 small_hill hypo_hill; do
   timeout -k 10 300 python3 tools/bench_kernels.py --model $m --scatter gather > $O/kernels_${m}_gather.json 2>/dev/null || exit 1

@@ -25,7 +25,7 @@ for mode in ("atomic", "gather"):
         keep = [rows[0]] + [r for r in rows[1:] if "c8::" in r[0]]
         csv.writer(open(os.path.join(dst, "%s_kernel_stats_wave_%s_100cube.csv" % (tag, mode)), "w")).writerows(keep)
         print("saved kernel stats", mode)
-    put("pmc_%s.json" % mode, "traffic_wave_%s_100cube.json" % mode)
+    put("pmc_%s.json" % mode, "traffic_%s_100cube.json" % mode)
 put("bench_default.json", "bench_default_wave_gather_100cube.json")
 put("bench_atomic.json", "bench_wave_atomic_100cube.json")
 put("bench_colored.json", "bench_wave_colored_100cube.json")
@@ -35,3 +35,8 @@ for m in ("small_J2", "hyper_J2", "small_hill", "hypo_hill"):
     put("kernels_%s.json" % m, "all_kernels_%s_100cube.json" % m)
     put("kernels_%s_gather.json" % m, "all_kernels_%s_100cube_gather.json" % m)
 put("kernels_tet4_gather.json", "all_kernels_tet4_1M_gather.json")
+put("k1_kernels.log", "forward_kernels_100cube.log")
+put("k3_kernels.log", "adjoint_kernels_100cube.log")
+put("bench_n2.json", "bench_n2_rehearsal_48cube_host_transport.json")
+put("bench_n4.json", "bench_n4_rehearsal_48cube_host_transport.json")
+put("gpu_tests.log", "gpu_tests.log")
