@@ -141,6 +141,12 @@ template <template <class> class ModelT> struct WaveLane {
   int iter;
   double R_norm_0;
   bool converged, failed;
+  // models with a local line search (uses_line_search): branch of the first evaluation, state of the search
+  int path;
+  double dxi[Model::NLOC];
+  double ls_alpha, ls_applied, ls_best_alpha, ls_best_phi, ls_phi0, ls_phi;
+  int ls_n;
+  bool ls_done;
 };
 
 template <class SH> C8_HD void load_point(SH const& sh, int pt, PointState<Dual>& g, bool prev) {
@@ -390,6 +396,112 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
   return ok;
 }
 
+// ---- local Newton iteration with line search in the 8-lanes-per-point layout (the lane-group form with its references:
+// local_newton_line_search, c8_assemble.hpp): lane = point*8 + d holds column d of J = dC/dxi in its tangents and hands it
+// to the point's eight lanes through sh.M[pt]; the values are replicated over the eight lanes, so they take the same
+// decisions.  The elimination works on the matrix in LDS (gj_solve_grouped): these models have no registers to spare.  On
+// exit sh.M[pt] holds dC/dxi of the last evaluation at the converged state, as after the plain iteration.
+template <int NL, bool PIN, class EX, class SH>
+C8_HD void local_newton_line_search_wave(EX& ex, SH& sh, ModelSettings const& ms) {
+  auto active = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
+  auto searching = [&](int lane) { return active(lane) && !ex.lane(lane).ls_done; };
+  while (ex.any(active)) {
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
+      auto& r = ex.lane(lane);
+      if (!active(lane)) return;
+      int const pt = lane >> 3, d = lane & 7;
+      if (r.iter == 1) r.path = r.m.evaluate(r.g, ms.abs_tol);
+      else r.m.evaluate(r.g, ms.abs_tol, true, r.path);
+      double nrm = 0.;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
+      double const C_norm = sqrt(nrm);
+      if (r.iter == 1) r.R_norm_0 = C_norm;
+      double const C_norm_rel = C_norm / r.R_norm_0;
+      if ((C_norm_rel < ms.rel_tol) || (C_norm < ms.abs_tol)) r.converged = true;
+      if (d < NL) C8_UNROLL for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.m.R[j].d;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) r.b[j] = -r.m.R[j].v;
+      r.ls_phi0 = 0.5 * C_norm * C_norm;
+    });
+    ex.sync();
+    if (!ex.any(active)) break;
+    bool const ok = gj_solve_grouped<NL, 8>(ex, [&](int lane) { return sh.M[lane >> 3]; },
+                                            [&](int lane) { return ex.lane(lane).b; }, active);
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
+      auto& r = ex.lane(lane);
+      if (!active(lane)) return;
+      if (!ok) { r.failed = true; r.iter = ms.max_iters + 1; r.ls_done = true; return; }
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) { r.dxi[j] = r.b[j]; r.m.xi[j].v += r.b[j]; }  // the full Newton step
+      r.ls_alpha = 1.;
+      r.ls_applied = 1.;
+      r.ls_best_alpha = 1.;
+      r.ls_best_phi = 1.7976931348623157e308;
+      r.ls_n = 1;
+      r.ls_done = false;
+    });
+    while (ex.any(searching)) {
+      ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);  // eval(alpha): the trial step on the forced branch
+        auto& r = ex.lane(lane);
+        if (!searching(lane)) return;
+        int const pt = lane >> 3, d = lane & 7;
+        double const diff = r.ls_alpha - r.ls_applied;
+        r.ls_applied = r.ls_alpha;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) r.m.xi[j].v += diff * r.dxi[j];
+        r.path = r.m.evaluate(r.g, ms.abs_tol, true, r.path);
+        double nrm = 0.;
+        C8_UNROLL
+        for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
+        double const C_alpha = sqrt(nrm);
+        r.ls_phi = 0.5 * C_alpha * C_alpha;
+        if (d < NL) C8_UNROLL for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.m.R[j].d;
+      });
+      ex.sync();
+      ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
+        auto& r = ex.lane(lane);
+        if (!searching(lane)) return;
+        int const pt = lane >> 3;
+        double slope = 0.;  // phi'(alpha) = C . (J dxi)
+        C8_UNROLL
+        for (int i = 0; i < NL; ++i) {
+          double Jd = 0.;
+          C8_UNROLL
+          for (int c = 0; c < NL; ++c) Jd += sh.M[pt][i][c] * r.dxi[c];
+          slope += r.m.R[i].v * Jd;
+        }
+        double const phi_0 = r.ls_phi0, dphi_0 = -2. * phi_0;
+        if (r.ls_phi < r.ls_best_phi) { r.ls_best_phi = r.ls_phi; r.ls_best_alpha = r.ls_alpha; }
+        if (r.ls_phi <= phi_0 + r.ls_alpha * (ms.ls_c1 * dphi_0)) { r.ls_done = true; return; }  // sufficient decrease
+        // minimiser of the cubic through (0, phi_0, dphi_0) and (alpha, phi, slope), safeguarded (line_search.hpp:56-66,:121-123)
+        double const a = r.ls_alpha;
+        double const d1 = dphi_0 + slope - 3. * (phi_0 - r.ls_phi) / (0. - a);
+        double const radicand = d1 * d1 - dphi_0 * slope;
+        double alpha_model = 0.5 * a;
+        if (!(radicand < 0.)) {
+          double const d2 = sqrt(radicand);
+          double const denom = slope - dphi_0 + 2. * d2;
+          if (denom != 0.) alpha_model = a - a * (slope + d2 - d1) / denom;
+        }
+        double const lo = ms.ls_bmin * a, hi = ms.ls_bmax * a;
+        r.ls_alpha = fmin(fmax(alpha_model, lo), hi);
+        r.ls_n++;
+        if (r.ls_n > ms.ls_max_evals) { r.ls_alpha = r.ls_best_alpha; r.ls_done = true; }  // the lowest-merit step
+      });
+      ex.sync();
+    }
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);  // move the local state to the accepted step
+      auto& r = ex.lane(lane);
+      if (!active(lane) || r.failed) return;
+      double const diff = r.ls_alpha - r.ls_applied;
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) r.m.xi[j].v += diff * r.dxi[j];
+      r.iter++;
+    });
+  }
+}
+
 // ADJOINT = false: eval_forward_jacobian (evaluations.cpp:12-154)
 // ADJOINT = true : eval_adjoint_jacobian (evaluations.cpp:349-526): no local solve (stored xi), the element
 //                  matrix is scattered transposed, and the right-hand side is -dJ/dx + f + (dxi/dx)^T g with
@@ -529,7 +641,9 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       }
     }
   });
-  if (Model::HAS_LOCAL && !ADJOINT) {
+  if constexpr (uses_line_search<Model>::value) {
+    if (!ADJOINT) local_newton_line_search_wave<NL, PIN>(ex, sh, ms);
+  } else if (Model::HAS_LOCAL && !ADJOINT) {
     auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
     ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = r.m.trial(r.g); });  // once per point, not per iteration
     while (ex.any(running)) {

@@ -665,9 +665,7 @@ template <template <class> class ModelT> struct WaveKernel<Elem<C8_HEX8>, ModelT
 };
 
 template <class E, template <class> class ModelT> static KernelSet kernel_set() {
-  // models with a local line search (Hosford / Barlat) run through the lane-group kernels on every element type: the
-  // wave-per-element kernels carry their own Newton iteration and are not instantiated for them
-  using WK = std::conditional_t<uses_line_search<ModelT<Dual>>::value, WaveKernel<void, ModelT>, WaveKernel<E, ModelT>>;
+  using WK = WaveKernel<E, ModelT>;
   KernelSet ks;
   ks.forward_jacobian = &launch_forward<E, ModelT>;
   ks.forward_jacobian_wave = WK::get();

@@ -322,6 +322,9 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_hill") run_qoi_wave<SmallHill>(c);
     else if (model == "isotropic_elastic") run_qoi_wave<IsotropicElastic>(c);
     else if (model == "hypo_hill") run_qoi_wave<HypoHill>(c);
+    else if (model == "small_hosford") run_qoi_wave<SmallHosford>(c);
+    else if (model == "hypo_hosford") run_qoi_wave<HypoHosford>(c);
+    else if (model == "hypo_barlat") run_qoi_wave<HypoBarlat>(c);
     else return -2;
     return 0;
   }
@@ -333,6 +336,9 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_hill") run_residual_wave<SmallHill>(c);
     else if (model == "isotropic_elastic") run_residual_wave<IsotropicElastic>(c);
     else if (model == "hypo_hill") run_residual_wave<HypoHill>(c);
+    else if (model == "small_hosford") run_residual_wave<SmallHosford>(c);
+    else if (model == "hypo_hosford") run_residual_wave<HypoHosford>(c);
+    else if (model == "hypo_barlat") run_residual_wave<HypoBarlat>(c);
     else return -2;
     return 0;
   }
@@ -344,6 +350,9 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_hill") run_wave_adjoint<SmallHill>(c);
     else if (model == "isotropic_elastic") run_wave_adjoint<IsotropicElastic>(c);
     else if (model == "hypo_hill") run_wave_adjoint<HypoHill>(c);
+    else if (model == "small_hosford") run_wave_adjoint<SmallHosford>(c);
+    else if (model == "hypo_hosford") run_wave_adjoint<HypoHosford>(c);
+    else if (model == "hypo_barlat") run_wave_adjoint<HypoBarlat>(c);
     else return -2;
     return 0;
   }
@@ -355,6 +364,9 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     else if (model == "small_hill") run_wave<SmallHill>(c);
     else if (model == "isotropic_elastic") run_wave<IsotropicElastic>(c);
     else if (model == "hypo_hill") run_wave<HypoHill>(c);
+    else if (model == "small_hosford") run_wave<SmallHosford>(c);
+    else if (model == "hypo_hosford") run_wave<HypoHosford>(c);
+    else if (model == "hypo_barlat") run_wave<HypoBarlat>(c);
     else return -2;
     return 0;
   }

@@ -11,12 +11,13 @@ from parity_cases import (CASES_LINE_SEARCH, LOCAL_LINE_SEARCH, check_adjoint_ch
                           two_steps)
 
 
-def pair(kind, model, params):
+def pair(kind, model, params, wave=False):
     et, c, conn = mesh_of(kind)
     orc = ol.Oracle(et, c, conn, model, params)
     orc.set_local_line_search(*LOCAL_LINE_SEARCH)
     dut = em.Emul(et, c, conn, model, params)
     dut.set_local_line_search(*LOCAL_LINE_SEARCH)
+    dut.wave = wave
     return orc, dut, c
 
 
@@ -30,6 +31,17 @@ def test_emulated_line_search_models_match_oracle(model, params, eps, kind):
     check_residual(orc, dut, c, eps, 1e-12)
     check_adjoint_chain(orc, dut, c, model, eps, 1e-12)
     assert (two_steps(orc, c, eps)[2][2][:, :, 6] > 0).mean() > 0.3  # the plastic branch really ran
+
+
+@pytest.mark.parametrize("model,params,eps", CASES_LINE_SEARCH)
+def test_emulated_wave_kernels_of_line_search_models_match_oracle(model, params, eps):
+    # hex8 through the wave-per-element kernels: the Newton + line-search iteration in the 8-lanes-per-point layout
+    # (local_newton_line_search_wave), every entry point
+    orc, dut, c = pair("hex8", model, params, wave=True)
+    check_forward(orc, dut, c, model, eps, 1e-12)
+    check_residual(orc, dut, c, eps, 1e-12)
+    check_adjoint_chain(orc, dut, c, model, eps, 1e-12)
+    assert (two_steps(orc, c, eps)[2][2][:, :, 6] > 0).mean() > 0.3
 
 
 def test_without_the_line_search_the_stiff_exponent_fails_on_both_sides():

@@ -1,6 +1,7 @@
 """`-m gpu`: the Hosford / Barlat family on the device: `small_hosford`, `hypo_hosford`,
-`hypo_barlat` through the lane-group kernels on tet4 and hex8 (local Newton iteration with forced branch and line search
-inside the assembly kernel), every entry point against the oracle at 1e-12, and the reference's two decks end to end."""
+`hypo_barlat` through the lane-group kernels on tet4 and hex8 and through the wave-per-element kernels on hex8 (local Newton
+iteration with forced branch and line search inside the assembly kernel), every entry point against the oracle at 1e-12, and
+the reference's two decks end to end."""
 import json
 import os
 
@@ -23,24 +24,50 @@ def test_line_search_models_match_oracle(model, params, eps, kind, scatter):
     et, c, conn = mesh_of(kind)
     orc = ol.Oracle(et, c, conn, model, params)
     orc.set_local_line_search(*LOCAL_LINE_SEARCH)
-    # "default": the library's own choice -- staged K1 (and K3 on tet4); the hex8 K3 of these models has no
-    # wave-per-element kernel to stage from and runs in colour batches
+    # "default": the library's own choice -- the staged assembly of K1 and K3; on hex8 through the wave-per-element kernels
     gpu = GpuBackend(et, c, conn, model, params, scatter=None if scatter == "default" else scatter, line_search=LOCAL_LINE_SEARCH)
     check_forward(orc, gpu, c, model, eps, 1e-12)
     check_residual(orc, gpu, c, eps, 1e-12)
     check_adjoint_chain(orc, gpu, c, model, eps, 1e-12)
 
 
-def test_hex8_default_runs_the_lane_group_kernels_staged():
-    # no wave-per-element kernels for these models: `auto` means the lane-group kernels, `wave` is refused; the library
-    # default stays the staged assembly
+@pytest.mark.parametrize("scatter", ["colored", "default"])
+@pytest.mark.parametrize("model,params,eps", CASES_LINE_SEARCH)
+def test_hex8_lane_group_kernels_match_oracle(model, params, eps, scatter):
+    # `slot`: one thread per point and DOF slot, the kernels these models ran through before they had wave-per-element ones
+    # (their adjoint Jacobian kernel cannot stage on hex8: colour batches in the default mode)
+    from gpu_backend import GpuBackend
+    et, c, conn = mesh_of("hex8")
+    orc = ol.Oracle(et, c, conn, model, params)
+    orc.set_local_line_search(*LOCAL_LINE_SEARCH)
+    gpu = GpuBackend(et, c, conn, model, params, scatter=None if scatter == "default" else scatter, line_search=LOCAL_LINE_SEARCH)
+    gpu.asm.set_kernel("slot")
+    check_forward(orc, gpu, c, model, eps, 1e-12)
+    check_residual(orc, gpu, c, eps, 1e-12)
+    check_adjoint_chain(orc, gpu, c, model, eps, 1e-12)
+
+
+def test_hex8_wave_and_lane_group_kernels_agree():
+    # the same Newton + line-search decisions in both layouts: state, matrices and right-hand side to rounding
+    import torch
     from calibr8_amd import Assembler
-    from calibr8_amd.lib import C8Error
+    from meshes import prescribed_fields
     et, c, conn = mesh_of("hex8")
     asm = Assembler(8, c, conn, "hypo_barlat", BARLAT, line_search=LOCAL_LINE_SEARCH)
     assert asm.scatter == "gather" and asm.nloc == 7
-    with pytest.raises(C8Error):
-        asm.set_kernel("wave")
+    u_h, p_h = prescribed_fields(c, 0.006, ramp=True, perturb=5e-2)
+    u, p = asm.dev(u_h), asm.dev(p_h)
+    z = torch.zeros_like(u), torch.zeros_like(p)
+    out = {}
+    for k in ("wave", "slot"):
+        asm.set_kernel(k)
+        xi0, xi, ls = asm.new_state(), asm.new_state(), asm.new_linsys()
+        asm.forward_jacobian(u, p, z[0], z[1], xi0, xi, ls)
+        assert asm.status() == 0
+        out[k] = (xi.clone(), ls.flat.clone())
+    assert float((out["wave"][0][:, :, 6] > 0).double().mean()) > 0.3
+    assert float((out["wave"][0] - out["slot"][0]).abs().max()) < 1e-12
+    assert float((out["wave"][1] - out["slot"][1]).abs().max()) < 1e-11 * float(out["slot"][1].abs().max())
 
 
 def notch():

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--model", default="small_J2", choices=["small_J2", "hyper_J2", "small_hill", "elastic", "hypo_hill", "small_hosford", "hypo_hosford",
                                                             "hypo_barlat", "small_hill_plane_strain", "hyper_J2_plane_strain", "hypo_hill_plane_strain",
                                                             "small_hill_plane_stress", "hyper_J2_plane_stress", "hypo_hill_plane_stress"])
+    ap.add_argument("--eps", type=float, default=None, help="strain of the prescribed state (default 0.004; hypo_barlat 0.006; the Hosford models 0.002: one step to 0.004 is beyond their local Newton iteration)")
     ap.add_argument("--tet", action="store_true", help="split every hex into 6 tet4 (the reference's element type)")
     ap.add_argument("--tri", action="store_true", help="a tri3 mesh of 2 * (7 * edge)^2 elements (the reference's 2-D element type; 2-D models)")
     args = ap.parse_args()
@@ -51,7 +52,7 @@ def main():
                     **({"line_search": LOCAL_LINE_SEARCH} if line_search else {}))
     asm.set_active(0, ACTIVE[args.model][:4])
     asm.set_async(True)
-    u_h, p_h = prescribed_fields(coords, 0.006 if args.model == "hypo_barlat" else 0.004, ramp=True)
+    u_h, p_h = prescribed_fields(coords, args.eps if args.eps else {"hypo_barlat": 0.006, "small_hosford": 0.002, "hypo_hosford": 0.002}.get(args.model, 0.004), ramp=True)
     if args.tri:
         from meshes import fields_for
         u_h, p_h = fields_for(2, u_h, p_h)
@@ -80,9 +81,7 @@ def main():
 
     res = {}
     # staged (gather) mode: the hex8 lane-group adjoint kernel cannot stage, time the wave-per-element kernels only
-    variants = ("slot",) if (args.tet or args.tri or line_search) else (("wave",) if args.scatter == "gather" else ("wave", "slot"))
-    if line_search and not args.tet and args.scatter in ("gather", "default"):
-        variants = ("auto",)  # hex8: the default mode stages K1 and runs K3 in colour batches (no explicit lane-group K3 in this mode)
+    variants = ("slot",) if (args.tet or args.tri) else (("wave",) if args.scatter in ("gather", "default") else ("wave", "slot"))
     for k in variants:
         asm.set_kernel(k)
         res["forward_jacobian_" + k] = timeit(lambda: asm.forward_jacobian(u, p, u0, p0, xi0, xi, ls))
