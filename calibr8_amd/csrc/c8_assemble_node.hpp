@@ -61,13 +61,6 @@ template <class E, class ModelD, int MAXDEG, bool MANY> struct NodeShared {
   C8_HD double* acc(int pos) { return buf + (MANY ? NREC : 0) + pos * LDA; }
 };
 
-// nodes of the point's shape table that phase A fetches together with the nodal values, one memory round trip before their
-// use (0 .. 8; tuning switch, same results).  Every prefetched node costs six registers over the phase: with none the kernel
-// runs three waves per SIMD, with all eight two.
-#ifndef C8_TUNE_NODE_PREFETCH
-#define C8_TUNE_NODE_PREFETCH 0
-#endif
-constexpr int NODE_PFN = C8_TUNE_NODE_PREFETCH;
 #ifndef C8_TUNE_NODE_HAHEAD
 #define C8_TUNE_NODE_HAHEAD 3
 #endif
@@ -78,8 +71,6 @@ template <int MAXDEG> struct NodeLane {
   double a00[N00], a01[N01], a10[N01], a11;  // current values of this lane's CSR entries
   double bold;                               // ... and of its residual entry (lanes 0..3)
   double rs;
-  // phase A: operands of this lane's point, fetched with the nodal values (one memory round trip earlier than their use)
-  double dn[NODE_PFN > 0 ? NODE_PFN : 1][3], xo[8], wdv;
   int e, a, pos;
   bool valid;
 };
@@ -162,21 +153,6 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       // phase B's operand of this lane (column node m): position of m in the node's graph row
       r.pos = ga.pos[((size_t)e * E::NN + m) * E::NN + a];
       int const nd = mt.conn[(size_t)e * E::NN + m];
-      {  // this lane's point in the second half of the phase: pt = m
-        double const* const t = mt.shape + (size_t)e * SHAPE_STRIDE;
-        C8_UNROLL
-        for (int k = 0; k < NODE_PFN; ++k) {
-          r.dn[k][0] = t[(m * E::NN + k) * 3 + 0];
-          r.dn[k][1] = t[(m * E::NN + k) * 3 + 1];
-          r.dn[k][2] = t[(m * E::NN + k) * 3 + 2];
-        }
-        if (NODE_PFN > 0) {
-          r.wdv = t[SHAPE_WDV + m];
-          size_t const q0 = ((size_t)e * E::NP0 + m) * NL;
-          C8_UNROLL
-          for (int j = 0; j < NL; ++j) r.xo[j] = fa.xi_prev[q0 + j];
-        }
-      }
       double* const nv = sh.nodal[s][m];
       nv[0] = fa.u[(size_t)nd * 3 + 0]; nv[1] = fa.u[(size_t)nd * 3 + 1]; nv[2] = fa.u[(size_t)nd * 3 + 2];
       nv[3] = fa.p[nd];
@@ -202,16 +178,25 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
         C8_UNROLL
         for (int j = 0; j < NL; ++j) gx[j] = aa.g[((size_t)e * E::NP0 + pt) * NL + j];
       }
-      // interpolation (global_residual.cpp:289-332): the same sequential sums over the nodes as interp_ab; four nodes'
-      // operands in flight at a time
+      // interpolation (global_residual.cpp:289-332).  The table is skewed (shape_dn_offset): at step i the element's eight
+      // lanes read row i, this lane the entry of node m = (i - pt) mod 8 -- the sum over the nodes starts at node -pt mod 8
+      // and wraps; the row node's own entry (g below) is kept when it comes by.  Four nodes' operands in flight at a time
       double q[WQ];
       C8_UNROLL
       for (int c = 0; c < WQ; ++c) q[c] = 0.;
+#ifndef C8_TUNE_NODE_GSEL
+#define C8_TUNE_NODE_GSEL 0
+#endif
+      double g[3] = {0., 0., 0.};
       C8_UNROLL
-      for (int m = 0; m < E::NN; ++m) {
-        bool const pf = m < NODE_PFN;
-        double const d0 = pf ? r.dn[pf ? m : 0][0] : t[(pt * E::NN + m) * 3 + 0], d1 = pf ? r.dn[pf ? m : 0][1] : t[(pt * E::NN + m) * 3 + 1],
-                     d2 = pf ? r.dn[pf ? m : 0][2] : t[(pt * E::NN + m) * 3 + 2];
+      for (int i = 0; i < E::NN; ++i) {
+        int const m = (i - pt) & 7;
+        double const* const row = t + i * 24;
+        double const d0 = row[m * 2 + 0], d1 = row[m * 2 + 1], d2 = row[16 + m];
+        if (C8_TUNE_NODE_GSEL) {
+          bool const own = m == a;
+          g[0] = own ? d0 : g[0]; g[1] = own ? d1 : g[1]; g[2] = own ? d2 : g[2];
+        }
         double const Nm = Np.at_node(m);
         double const* const nv = sh.nodal[s][m];
         double const u0 = nv[0], u1 = nv[1], u2 = nv[2], pm = nv[3];
@@ -220,7 +205,14 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
         q[6] += u2 * d0; q[7] += u2 * d1; q[8] += u2 * d2;
         q[9] += pm * Nm;
         q[10] += pm * d0; q[11] += pm * d1; q[12] += pm * d2;
-        if (m == 3 || m == 7) {
+#ifndef C8_TUNE_NODE_AGROUP
+#define C8_TUNE_NODE_AGROUP 8
+#endif
+#ifndef C8_TUNE_NODE_AGROUP_ADJ
+#define C8_TUNE_NODE_AGROUP_ADJ 2
+#endif
+        // nodes whose operands are in flight together: as measured (forward 8: 4.51 ms, 4: 4.70, 2: 4.57; adjoint 2: 5.39, 4: 5.55, 8: 5.66)
+        if ((i + 1) % (ADJ ? C8_TUNE_NODE_AGROUP_ADJ : C8_TUNE_NODE_AGROUP) == 0) {
           C8_UNROLL
           for (int c = 0; c < 13; ++c) C8_PIN(q[c]);
           C8_SCHED_FENCE();
@@ -230,7 +222,7 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       size_t const q0 = ((size_t)e * E::NP0 + pt) * NL;
       double xi_old[NL];
       C8_UNROLL
-      for (int j = 0; j < NL; ++j) xi_old[j] = NODE_PFN > 0 ? r.xo[j] : fa.xi_prev[q0 + j];
+      for (int j = 0; j < NL; ++j) xi_old[j] = fa.xi_prev[q0 + j];
       int const es = mt.elem_set ? mt.elem_set[e] : 0;
       typename Model::ClosedForm cf;
       Model::closed_form(mt.params + (size_t)es * Model::NPARAMS, q, xi_old, ms.abs_tol, t[SHAPE_H], ms.stab_mult, cf, true);
@@ -239,8 +231,8 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
         for (int j = 0; j < NL; ++j) fa.xi[q0 + j] = cf.xi[j];
       }
       C8_NSTAMP(8);
-      double const w = NODE_PFN > 0 ? r.wdv : t[SHAPE_WDV + pt];
-      double const g[3] = {t[(pt * E::NN + a) * 3 + 0], t[(pt * E::NN + a) * 3 + 1], t[(pt * E::NN + a) * 3 + 2]};
+      double const w = t[SHAPE_WDV + pt];
+      if (!C8_TUNE_NODE_GSEL) { g[0] = t[shape_dn_offset(pt, a, 0)]; g[1] = t[shape_dn_offset(pt, a, 1)]; g[2] = t[shape_dn_offset(pt, a, 2)]; }
       double const Na = Np.at_node(a);
       double* const rc = sh.rec(s, pt);
       double el[2];
@@ -287,19 +279,21 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
       double const* const t = mt.shape + (size_t)r.e * SHAPE_STRIDE;
       HexShape<E> const Nn = HexShape<E>::of_node(m);
       double const el[2] = {sh.el[s][0], sh.el[s][1]};
-      // dN_m/dx of this lane's column node, C8_TUNE_NODE_HAHEAD points ahead of the arithmetic (the element's table is in
-      // L1 / L2 by now)
+      // dN_m/dx of this lane's column node: at step i the element's eight lanes read row i of the skewed table, this lane
+      // the entry of point (i - m) mod 8; C8_TUNE_NODE_HAHEAD steps ahead of the arithmetic (the element's table is in L1 /
+      // L2 by now)
       constexpr int AH = C8_TUNE_NODE_HAHEAD;
       double hq[AH + 1][3];
       C8_UNROLL
-      for (int k = 0; k < AH; ++k) { hq[k][0] = t[(k * E::NN + m) * 3 + 0]; hq[k][1] = t[(k * E::NN + m) * 3 + 1]; hq[k][2] = t[(k * E::NN + m) * 3 + 2]; }
+      for (int k = 0; k < AH; ++k) { hq[k][0] = t[k * 24 + m * 2 + 0]; hq[k][1] = t[k * 24 + m * 2 + 1]; hq[k][2] = t[k * 24 + 16 + m]; }
       C8_UNROLL
-      for (int pt = 0; pt < E::NP0; ++pt) {
+      for (int i = 0; i < E::NP0; ++i) {
+        int const pt = (i - m) & 7;
         hq[AH][0] = hq[AH][1] = hq[AH][2] = 0.;
-        if (pt + AH < E::NP0) {
-          hq[AH][0] = t[((pt + AH) * E::NN + m) * 3 + 0];
-          hq[AH][1] = t[((pt + AH) * E::NN + m) * 3 + 1];
-          hq[AH][2] = t[((pt + AH) * E::NN + m) * 3 + 2];
+        if (i + AH < E::NP0) {
+          hq[AH][0] = t[(i + AH) * 24 + m * 2 + 0];
+          hq[AH][1] = t[(i + AH) * 24 + m * 2 + 1];
+          hq[AH][2] = t[(i + AH) * 24 + 16 + m];
         }
         double const hc[3] = {hq[0][0], hq[0][1], hq[0][2]};
         Model::closed_form_block(sh.rec(s, pt), el, hc, Nn.at_point(pt), r.J);

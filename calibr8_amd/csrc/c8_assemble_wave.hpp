@@ -38,6 +38,13 @@ constexpr int WF = 13;   // point fluxes: Gu (0..8 row-major), Vp (9), Gp (10..1
 // Per element: dN[pt][n][3] (lane = pt*8 + n reads its three values contiguously), w dv [pt], element size h.
 constexpr int SHAPE_STRIDE = 208;  // 192 + 8 + 1, padded to a multiple of 64 bytes
 constexpr int SHAPE_WDV = 192, SHAPE_H = 200;
+// dN/dx of (point pt, node m), component d, within an element's cached table.  The 8 x 8 entries are stored SKEWED: row
+// r = (pt + m) mod 8, column m -- per row first the components 0 and 1 of the eight columns (16 doubles), then their
+// components 2 (8 doubles).  The eight lanes of an element then read ONE row of 192 contiguous bytes per step whether a lane
+// owns a point and walks the nodes (lane pt at step i: node (i - pt) mod 8) or owns a node and walks the points (lane m at
+// step i: point (i - m) mod 8): the row-per-node kernels (c8_assemble_node.hpp) are bound by the number of 64-byte segments
+// their loads touch, and a row-major table costs a lane-per-point reader eight times the segments.
+C8_HD constexpr int shape_dn_offset(int pt, int m, int d) { return ((pt + m) & 7) * 24 + (d < 2 ? m * 2 + d : 16 + m); }
 template <class E> struct ShapeShared {
   double X[E::NN][3];
   double N[E::NP0][E::NN];
@@ -64,9 +71,9 @@ template <class E, class EX> C8_HD void store_shape_tables(EX& ex, ShapeShared<E
   ex.each([&](int lane) {
     double* const t = tab + (size_t)e * SHAPE_STRIDE;
     int const pt = lane >> 3, n = lane & 7;
-    t[lane * 3 + 0] = sh.dN[pt][n][0];
-    t[lane * 3 + 1] = sh.dN[pt][n][1];
-    t[lane * 3 + 2] = sh.dN[pt][n][2];
+    t[shape_dn_offset(pt, n, 0)] = sh.dN[pt][n][0];
+    t[shape_dn_offset(pt, n, 1)] = sh.dN[pt][n][1];
+    t[shape_dn_offset(pt, n, 2)] = sh.dN[pt][n][2];
     if (lane < E::NP0) t[SHAPE_WDV + lane] = sh.wdv[lane];
     if (lane == E::NP0) t[SHAPE_H] = sh.h;
     if (lane > E::NP0 && lane < SHAPE_STRIDE - SHAPE_H + E::NP0) t[SHAPE_H + lane - E::NP0] = 0.;  // padding
@@ -76,14 +83,17 @@ template <class E, class EX> C8_HD void store_shape_tables(EX& ex, ShapeShared<E
 // the lane's share of the cached tables: issued with the first loads of an element ...
 template <class E, class R> C8_HD void load_cached_shape(R& r, MeshTables const& mt, int e, int lane) {
   double const* const t = mt.shape + (size_t)e * SHAPE_STRIDE;
-  r.dn[0] = t[lane * 3 + 0];
-  r.dn[1] = t[lane * 3 + 1];
-  r.dn[2] = t[lane * 3 + 2];
+  // lane = (row, column) of the skewed table, i.e. the entry of point (row - column) mod 8 and node `column`: eight lanes
+  // read one row (commit_cached_shape puts the entry where it belongs)
+  int const row = lane >> 3, col = lane & 7;
+  r.dn[0] = t[row * 24 + col * 2 + 0];
+  r.dn[1] = t[row * 24 + col * 2 + 1];
+  r.dn[2] = t[row * 24 + 16 + col];
   r.sx = (lane <= E::NP0) ? t[SHAPE_WDV + lane] : 0.;  // lanes 0..7: w dv of point `lane`; lane 8: h
 }
 // ... and committed to LDS beside the nodal data (N is a constant of the reference element)
 template <class E, class R, class SH> C8_HD void commit_cached_shape(R const& r, SH& sh, int lane) {
-  int const pt = lane >> 3, n = lane & 7;
+  int const n = lane & 7, pt = ((lane >> 3) - n) & 7;  // the entry this lane fetched (load_cached_shape)
   double xi[3], w;
   E::point(0, pt, xi, w);
   sh.N[pt][n] = E::N(n, xi);

@@ -661,7 +661,9 @@ def test_full_size_million_elements_properties():
     la, xa = assemble("atomic")
     lg, xg = assemble("gather")
     lg2, _ = assemble("gather")
-    assert torch.equal(lg.flat, lg2.flat) and torch.equal(xa, xg)
+    assert torch.equal(lg.flat, lg2.flat)  # bitwise reproducible
+    # the row-per-node kernel sums the interpolation over the nodes in a rotated order (skewed shape table): same state to rounding
+    assert rel(xg, xa) < 1e-13
     assert rel(lg.flat, la.flat) < 1e-13
     del lg2
     lc, _ = assemble("colored")
@@ -807,7 +809,9 @@ def test_full_size_million_tets_properties():
     lg, xg = assemble("gather")
     lg2, _ = assemble("gather")
     lc, _ = assemble("colored")
-    assert torch.equal(lg.flat, lg2.flat) and torch.equal(xa, xg)
+    assert torch.equal(lg.flat, lg2.flat)  # bitwise reproducible
+    # the row-per-node kernel sums the interpolation over the nodes in a rotated order (skewed shape table): same state to rounding
+    assert rel(xg, xa) < 1e-13
     assert rel(lg.flat, la.flat) < 1e-13 and rel(lc.flat, la.flat) < 1e-13
     assert 0.3 < float((xa[:, :, 6] > 0).double().mean()) < 0.7
     Ru = la.b[0].view(-1, 3)
@@ -889,7 +893,8 @@ def test_full_size_notched_specimen_properties():
     asm.set_scatter("atomic")
     l1b.zero()
     assert asm.forward_jacobian(u, p, z, zp, xi0, xib, l1b) == 0
-    assert float((l1b.flat - l1.flat).abs().max() / l1.flat.abs().max()) < 1e-13 and torch.equal(xi, xib)
+    assert float((l1b.flat - l1.flat).abs().max() / l1.flat.abs().max()) < 1e-13
+    assert float((xi - xib).abs().max() / xi.abs().max()) < 1e-13  # another summation order over the nodes (skewed shape table)
     del l1b, xib
     asm.set_scatter("gather")
     # (2)

@@ -17,6 +17,10 @@ GROUPS = [
     ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS"],
     ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
     ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"], ["GRBM_GUI_ACTIVE"],
+    # 9-12: the vector memory pipeline (address unit, L1): busy and stall cycles summed over the CUs
+    ["TA_TA_BUSY_sum", "TA_BUSY_avr", "TA_FLAT_WAVEFRONTS_sum"], ["TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TCP_TOTAL_ACCESSES_sum"],
+    ["TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"],
+    ["TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TD_TD_BUSY_sum", "TCP_TCC_READ_REQ_LATENCY_sum"],
 ]
 
 
