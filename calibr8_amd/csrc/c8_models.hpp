@@ -578,7 +578,7 @@ template <class T> struct SmallHill {
   static constexpr bool FINITE_DEF = false, HAS_LOCAL = true;
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 2;
   static constexpr int WAVE_BLOCKS_PER_CU_K4 = 2;  // waves per SIMD of the local-adjoint wave kernel
-  static constexpr bool GJ_XLANE_JAC = true, GJ_XLANE_K4 = true;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = true;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured (round 3: LDS in K1 / K3)
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // local Newton of the wave kernel: matrix columns in registers
   using Trial = NoTrial;
   C8_HD Trial trial(PointState<T> const&) const { return {}; }
@@ -650,10 +650,17 @@ template <class T> struct HypoHill {
   static constexpr bool PIN_PHASES_K1 = true, PIN_PHASES_K3 = true;  // jacobian_wave: lane-derived values per phase (pin_phases), as measured
   static constexpr int NLOC = 7, NPARAMS = 11;
   static constexpr bool FINITE_DEF = true, HAS_LOCAL = true;
-  static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
+#ifndef C8_TUNE_HH_WAVES
+#define C8_TUNE_HH_WAVES 2
+#endif
+  static constexpr int WAVE_BLOCKS_PER_CU = C8_TUNE_HH_WAVES, WAVE_BLOCKS_PER_CU_ADJ = 1;
   static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;  // waves per SIMD of the local-adjoint wave kernel
-  static constexpr bool GJ_XLANE_JAC = true, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured (round 3: LDS in K1 / K3)
+#ifdef C8_TUNE_HH_NEWTON_LDS
+  static constexpr bool NEWTON_MATRIX_IN_LDS = true;
+#else
   static constexpr bool NEWTON_MATRIX_IN_LDS = false;  // with the DPP hand-over K1 takes 32.5 ms (39.2 with the matrix in LDS)
+#endif
   T params[NPARAMS];  // E nu Y R00 R11 R22 R01 R02 R12 S D  (hypo_hill.cpp:84-95)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // TC(00,01,02,11,12,22), alpha
   C8_HD static void init_variables(double* xi0) { C8_UNROLL for (int k = 0; k < NLOC; ++k) xi0[k] = 0.; }  // :123-131
@@ -1384,8 +1391,10 @@ template <class T> struct HyperJ2 {
   // registers and half the occupancy it takes 14.8 ms; the Jacobian kernels are faster at 2 workgroups per CU
   static constexpr int WAVE_BLOCKS_PER_CU = 2, WAVE_BLOCKS_PER_CU_ADJ = 1;
   static constexpr int WAVE_BLOCKS_PER_CU_K4 = 1;  // waves per SIMD of the local-adjoint wave kernel
-  static constexpr bool GJ_XLANE_JAC = true, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured
-  static constexpr bool NEWTON_MATRIX_IN_LDS = true;  // K1 spills with the matrix columns in registers (32.5 against 28.8 ms)
+  static constexpr bool GJ_XLANE_JAC = false, GJ_XLANE_K4 = false;  // pivot-column hand-over of the local solves (gj_solve_cols), as measured (round 3: LDS in K1 / K3)
+  // local Newton of the wave kernel: matrix columns in registers.  (Round 2: 32.5 ms against 28.8 with the matrix in LDS; since the
+  // phases form their lane-derived values themselves (PIN_PHASES_K1) the register form spills 12 B instead of 180: 18.4 against 21.5 ms)
+  static constexpr bool NEWTON_MATRIX_IN_LDS = false;
   T params[NPARAMS];  // E nu Y S D A n K  (hyper_J2.cpp:83-90)
   T xi[NLOC], xi_prev[NLOC], R[NLOC];  // zeta(6), Ie, alpha
   C8_HD static void init_variables(double* xi0) {  // :119-134
