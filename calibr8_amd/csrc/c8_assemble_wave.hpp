@@ -406,13 +406,57 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
   return ok;
 }
 
+// Model::trial for the local Newton iteration: its arguments (the point quantities, the previous local state, the parameters)
+// carry no tangent there -- the seeds sit in xi --, so it is evaluated in plain doubles (the model's double instantiation, the
+// arithmetic of the dual numbers' value parts) instead of dual numbers whose tangent halves are all zero.
+template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial trial_values(ModelT<Dual> const& m, PointState<Dual> const& g) {
+  using TD = typename ModelT<Dual>::Trial;
+  if constexpr (std::is_same<TD, NoTrial>::value) {
+    return TD{};
+  } else {
+    using T1 = typename ModelT<double>::Trial;
+    static_assert(sizeof(TD) == sizeof(T1) / sizeof(double) * sizeof(Dual), "Trial: an aggregate of T");
+    ModelT<double> md;
+    C8_UNROLL
+    for (int k = 0; k < ModelT<Dual>::NPARAMS; ++k) md.params[k] = m.params[k].v;
+    C8_UNROLL
+    for (int k = 0; k < ModelT<Dual>::NLOC; ++k) { md.xi[k] = m.xi[k].v; md.xi_prev[k] = m.xi_prev[k].v; }
+    PointState<double> gd;
+    C8_UNROLL
+    for (int k = 0; k < 3; ++k) { gd.u[k] = g.u[k].v; gd.grad_p[k] = g.grad_p[k].v; }
+    gd.p = g.p.v;
+    auto vals = [](Tens3<Dual> const& a) {
+      Tens3<double> b;
+      b.xx = a.xx.v; b.xy = a.xy.v; b.xz = a.xz.v; b.yx = a.yx.v; b.yy = a.yy.v; b.yz = a.yz.v; b.zx = a.zx.v; b.zy = a.zy.v; b.zz = a.zz.v;
+      return b;
+    };
+    gd.grad_u = vals(g.grad_u);
+    gd.grad_u_prev = vals(g.grad_u_prev);
+    T1 const t = md.trial(gd);
+    TD out;
+    double const* const src = reinterpret_cast<double const*>(&t);
+    Dual* const dst = reinterpret_cast<Dual*>(&out);
+    C8_UNROLL
+    for (int k = 0; k < (int)(sizeof(T1) / sizeof(double)); ++k) dst[k] = Dual(src[k]);
+    return out;
+  }
+}
+
 // ---- local Newton iteration with line search in the 8-lanes-per-point layout (the lane-group form with its references:
 // local_newton_line_search, c8_assemble.hpp): lane = point*8 + d holds column d of J = dC/dxi in its tangents and hands it
 // to the point's eight lanes through sh.M[pt]; the values are replicated over the eight lanes, so they take the same
 // decisions.  The elimination works on the matrix in LDS (gj_solve_grouped): these models have no registers to spare.  On
 // exit sh.M[pt] holds dC/dxi of the last evaluation at the converged state, as after the plain iteration.
-template <int NL, bool PIN, class EX, class SH>
+template <int NL, bool PIN, template <class> class ModelT, class EX, class SH>
 C8_HD void local_newton_line_search_wave(EX& ex, SH& sh, ModelSettings const& ms) {
+  // the kinematic part of the residual (Model::trial) once per point, in plain doubles (trial_values), not in every evaluation
+  constexpr bool CACHED = !std::is_same<typename ModelT<Dual>::Trial, NoTrial>::value;
+  if constexpr (CACHED)
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = trial_values<ModelT>(r.m, r.g); });
+  auto eval = [&](auto& r, bool force) __attribute__((always_inline)) {
+    if constexpr (CACHED) return r.m.evaluate(r.g, ms.abs_tol, r.trial, force, r.path);
+    else return r.m.evaluate(r.g, ms.abs_tol, force, r.path);
+  };
   auto active = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
   auto searching = [&](int lane) { return active(lane) && !ex.lane(lane).ls_done; };
   while (ex.any(active)) {
@@ -420,8 +464,8 @@ C8_HD void local_newton_line_search_wave(EX& ex, SH& sh, ModelSettings const& ms
       auto& r = ex.lane(lane);
       if (!active(lane)) return;
       int const pt = lane >> 3, d = lane & 7;
-      if (r.iter == 1) r.path = r.m.evaluate(r.g, ms.abs_tol);
-      else r.m.evaluate(r.g, ms.abs_tol, true, r.path);
+      if (r.iter == 1) { r.path = 0; r.path = eval(r, false); }
+      else eval(r, true);
       double nrm = 0.;
       C8_UNROLL
       for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
@@ -460,7 +504,7 @@ C8_HD void local_newton_line_search_wave(EX& ex, SH& sh, ModelSettings const& ms
         r.ls_applied = r.ls_alpha;
         C8_UNROLL
         for (int j = 0; j < NL; ++j) r.m.xi[j].v += diff * r.dxi[j];
-        r.path = r.m.evaluate(r.g, ms.abs_tol, true, r.path);
+        r.path = eval(r, true);
         double nrm = 0.;
         C8_UNROLL
         for (int j = 0; j < NL; ++j) nrm += r.m.R[j].v * r.m.R[j].v;
@@ -652,10 +696,10 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     }
   });
   if constexpr (uses_line_search<Model>::value) {
-    if (!ADJOINT) local_newton_line_search_wave<NL, PIN>(ex, sh, ms);
+    if (!ADJOINT) local_newton_line_search_wave<NL, PIN, ModelT>(ex, sh, ms);
   } else if (Model::HAS_LOCAL && !ADJOINT) {
     auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
-    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = r.m.trial(r.g); });  // once per point, not per iteration
+    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = trial_values<ModelT>(r.m, r.g); });  // once per point, not per iteration
     while (ex.any(running)) {
       ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
         auto& r = ex.lane(lane);
