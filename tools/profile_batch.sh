@@ -31,6 +31,12 @@ timeout -k 10 300 python3 tools/time_k1.py --kernels auto,wave --adjoint > $O/k3
 for m in small_J2 hyper_J2 small_hill hypo_hill; do
   timeout -k 10 300 python3 tools/bench_kernels.py --model $m --scatter gather > $O/kernels_${m}_gather.json 2>/dev/null || exit 1
 done
+for m in hypo_barlat small_hosford hypo_hosford; do  # the line-search models (wave-per-element kernels on hex8), library default mode
+  timeout -k 10 300 python3 tools/bench_kernels.py --model $m --scatter default --reps 3 > $O/kernels_${m}_default.json 2>/dev/null || exit 1
+done
 echo kernels done
+# the vector-memory pipeline of the row-per-node kernels (address unit / L1 busy and stall cycles)
+timeout -k 10 600 python3 tools/pmc_k1.py --match node_rows --groups 9,10,11,12,8,3 --out $O/pmc_node_ta.json -- --kernel auto > $O/pmc_node_ta.log 2>&1 || exit 1
+echo ta counters done
 timeout -k 10 400 python3 tools/bench_fractions.py > $O/fractions.json 2>/dev/null || exit 1
 echo all done

@@ -35,6 +35,9 @@ for m in ("small_J2", "hyper_J2", "small_hill", "hypo_hill"):
     put("kernels_%s.json" % m, "all_kernels_%s_100cube.json" % m)
     put("kernels_%s_gather.json" % m, "all_kernels_%s_100cube_gather.json" % m)
 put("kernels_tet4_gather.json", "all_kernels_tet4_1M_gather.json")
+for m in ("hypo_barlat", "small_hosford", "hypo_hosford"):
+    put("kernels_%s_default.json" % m, "all_kernels_%s_100cube_default.json" % m)
+put("pmc_node_ta.json", "pmc_node_ta.json")
 put("k1_kernels.log", "forward_kernels_100cube.log")
 put("k3_kernels.log", "adjoint_kernels_100cube.log")
 put("bench_n2.json", "bench_n2_rehearsal_48cube_host_transport.json")
