@@ -19,7 +19,7 @@
 //            stores the converged local state
 //   phase B  lane = (element s of the node, column node m)   the 4 x 4 block d R_(node,.) / d x_(m,.) summed over the
 //            element's eight points: 16 accumulators
-//   phase C  element by element, in ascending element order: blocks added into the node's row accumulator in LDS
+//   phase C  blocks added into the node's row accumulator in LDS, every entry summed in ascending element order
 //            (acc[position of the column node in the node's graph row][16])
 //   phase D  the finished rows added to (or assigned to) the four CSR blocks, the residual entries to b
 //
@@ -345,9 +345,22 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
     }
     ex.sync();
     C8_NSTAMP(3);
-    // ---- phase C: the elements' blocks into the row accumulator, one element after the other.  LDS operations of a
-    //      wavefront execute in order, so the sums into one entry are taken in ascending element order; within one
-    //      element the column nodes are distinct and so are the addresses ------------------------------------------
+    // ---- phase C: the elements' blocks into the row accumulator (ds_add_f64), the sums into one entry taken in ascending
+    //      element order --------------------------------------------------------------------------------------------
+#ifndef C8_TUNE_NODE_C_BY_ELEMENT
+    // all elements in one pass.  Lanes of one instruction that add to the same entry (a column node shared by several of the
+    // node's elements) are served by the LDS unit in ascending lane order, i.e. in ascending element order: the results are
+    // bitwise those of the element-by-element form below (measured on jiggled meshes, forward and adjoint, tools/README.md),
+    // which took eight times the LDS instructions (K1 4.68 -> 4.46 ms)
+    ex.each([&](int lane) {
+      auto& r = ex.lane(lane);
+      if ((lane >> 3) >= ne) return;
+      double* const ac = sh.acc(r.pos);
+      C8_UNROLL
+      for (int j = 0; j < 16; ++j) ex.lds_add(ac + j, r.J[j]);
+      if ((lane & 7) < 4) ex.lds_add(&sh.bsum[lane & 7], r.rs);
+    });
+#else  // one element after the other: within one element the column nodes are distinct and so are the addresses
     for (int s2 = 0; s2 < ne; ++s2) {
       ex.each([&](int lane) {
         auto& r = ex.lane(lane);
@@ -358,6 +371,7 @@ C8_HD void node_rows_closed(EX& ex, NodeShared<E, ModelT<Dual>, MAXDEG, MANY>& s
         if ((lane & 7) < 4) ex.lds_add(&sh.bsum[lane & 7], r.rs);
       });
     }
+#endif
     ex.sync();
     C8_NSTAMP(4);
   }
