@@ -428,13 +428,15 @@ template <class E> static hipError_t launch_gather_rows(GatherArgs const& ga, in
 
 // K1, one wavefront per node (c8_assemble_node.hpp): the node's rows formed from its elements with the model's closed form
 // and written once -- no element stage.  XCD x takes every 8th stripe of NODE_STRIPE consecutive nodes: neighbouring nodes
-// share their elements' shape tables and state in one L2, and the eight XCDs work on one region of the mesh at a time
-// (stripes of 64: 4.69 ms against 5.02 ms with one contiguous eighth of the nodes per XCD, gpurun_out/ab_xcd.log).
+// share their elements' shape tables and state in one L2, and the eight XCDs work on one region of the mesh at a time.
+// Measured on the 100^3 brick (K1 ms / K3 ms / HBM-side GB per assembly with FETCH_SIZE doubled): stripes of 64: 4.37 / 5.20 /
+// 16.9; 256: 4.33 / 5.12 / 13.9; 512: 4.36 / 5.21 / 13.0; 1024: 4.36 / 5.30 / 12.5; 2048: 4.36 / 5.28 / 12.3; 16384 and one
+// contiguous eighth of the nodes per XCD: 4.71 / - / 12.1 (profiles/README.md, round 3).
 #ifndef C8_NODE_WAVES
 #define C8_NODE_WAVES 3
 #endif
 #ifndef C8_TUNE_NODE_STRIPE
-#define C8_TUNE_NODE_STRIPE 64
+#define C8_TUNE_NODE_STRIPE 256
 #endif
 constexpr int NODE_STRIPE = C8_TUNE_NODE_STRIPE;
 template <class E, template <class> class ModelT, int MAXDEG, bool MANY>
