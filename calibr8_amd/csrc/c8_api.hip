@@ -659,6 +659,10 @@ int c8_solve_adjoint_local(c8_ctx* c, const c8_state* st, const double* const z[
   AdjointArgs aa{g, f, z[0], z[1], phi, nullptr, c->d_active, c8_qoi_args(c)};
   LaunchFn fn = c->ks.adjoint_local;
   if (c->ks.adjoint_local_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.adjoint_local_wave;
+  // the model's closed form of the local adjoint solve (hex8 small_J2), where the caller leaves the kernel choice to the library
+  if (c->ks.adjoint_local_closed && c->ms.closed_form && !c->subset && st->xi != st->xi_prev &&
+      (c->kernel_variant == C8_KERNEL_AUTO || c->kernel_variant == C8_KERNEL_NODE))
+    fn = c->ks.adjoint_local_closed;
   return run(c, fn, field_args(st), aa, SystemArgs{}, false, "c8_solve_adjoint_local");
 }
 

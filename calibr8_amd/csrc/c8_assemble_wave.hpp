@@ -1801,6 +1801,70 @@ C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const&
 }
 
 // =====================================================================================
+// K4 for hex8 models with a closed form of their local equations (Model::closed_form_local_adjoint), eight elements per
+// wavefront: solve_adjoint_local (evaluations.cpp:528-659) without dual numbers and without the elimination of dC/dxi.
+// Lane (element, point) rebuilds the point's geometry from the coordinates, interpolates grad u and grad z, takes the state
+// and the tangent data from the model's closed form (as the row-per-node assemblies do) and writes phi and g; f, which a
+// small-strain model leaves zero, is cleared by the wavefront as one contiguous block.
+// =====================================================================================
+template <class E, template <class> class ModelT, class EX>
+C8_HD void adjoint_local_closed_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const& mt, ModelSettings const& ms,
+                                      FieldArgs const& fa, AdjointArgs const& aa, int e0, int count) {
+  using Model = ModelT<Dual>;
+  constexpr int NL = Model::NLOC;
+  static_assert(E::NN == 8 && E::NP0 == 8 && E::SAME_POINTS && !Model::FINITE_DEF, "hex8, small strain");
+  ex.each([&](int lane) {
+    int const el = lane >> 3, n = lane & 7;
+    if (el >= count) return;
+    int const node = mt.conn[(size_t)(e0 + el) * E::NN + n];
+    C8_UNROLL
+    for (int d = 0; d < 3; ++d) {
+      sh.X[el][n][d] = mt.coords[(size_t)node * 3 + d];
+      sh.u[el][n][d] = fa.u[(size_t)node * 3 + d];
+      sh.z[el][n][d] = aa.z_u[(size_t)node * 3 + d];
+    }
+    sh.p[el][n] = fa.p[node];
+    sh.z[el][n][3] = aa.z_p[node];
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    if (el >= count || pt != 0) return;
+    sh.h[el] = group_elem_size<E>(sh, el);
+  });
+  ex.sync();
+  ex.each([&](int lane) {
+    int const el = lane >> 3, pt = lane & 7;
+    // f = -(dC/dx_prev)^T phi = 0: the wavefront's elements are consecutive, their f one block of count * NP0 * NDOF doubles
+    double* const fb = aa.f + (size_t)e0 * E::NP0 * E::NDOF;
+    C8_UNROLL
+    for (int k = 0; k < E::NP0 * E::NDOF / 8; ++k) {
+      int const idx = k * 64 + lane;
+      if (idx < count * E::NP0 * E::NDOF) fb[idx] = 0.;
+    }
+    if (el >= count) return;
+    int const e = e0 + el;
+    int const es = mt.elem_set ? mt.elem_set[e] : 0;
+    double const* const prm = mt.params + (size_t)es * Model::NPARAMS;
+    PointState<double> gq;
+    double ZG[13];
+    group_point_state<E, false>(sh, el, pt, gq, ZG);
+    double const q[WQ] = {gq.grad_u.xx, gq.grad_u.xy, gq.grad_u.xz, gq.grad_u.yx, gq.grad_u.yy, gq.grad_u.yz, gq.grad_u.zx, gq.grad_u.zy,
+                          gq.grad_u.zz, gq.p, gq.grad_p[0], gq.grad_p[1], gq.grad_p[2], gq.u[0], gq.u[1], gq.u[2]};
+    size_t const qp = (size_t)e * E::NP0 + pt;
+    double xi_old[NL], g_in[NL], phi[NL], g_out[NL];
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) { xi_old[j] = fa.xi_prev[qp * NL + j]; g_in[j] = aa.g[qp * NL + j]; }
+    typename Model::ClosedForm cf;
+    Model::closed_form(prm, q, xi_old, ms.abs_tol, sh.h[el], ms.stab_mult, cf, true);
+    Model::closed_form_local_adjoint(prm, cf.t, sh.wdv[el][pt], ZG, g_in, phi, g_out);
+    C8_UNROLL
+    for (int j = 0; j < NL; ++j) { aa.phi[qp * NL + j] = phi[j]; aa.g[qp * NL + j] = g_out[j]; }
+  });
+  ex.sync();
+}
+
+// =====================================================================================
 // K6 for hex8, eight elements per wavefront: eval_qoi (evaluations.cpp:662-756) and the load sum of preprocess_qoi
 // (:262-347): lane (element, point) evaluates the objective integrand once; one add per wavefront at the end.
 // =====================================================================================

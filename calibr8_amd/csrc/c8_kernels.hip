@@ -21,6 +21,7 @@ namespace c8 {
 #endif
 constexpr int BLOCK = C8_BLOCK;
 
+struct NoLane {};  // kernels whose lanes keep nothing between the phases
 template <class Lane> struct GpuExec {
   int k;
   Lane& L;
@@ -335,6 +336,25 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k
   param_gradient_wave8_flush(ex, shs[wib].red, aa);
 }
 
+// K4 in closed form (adjoint_local_closed_wave8): eight consecutive elements per wavefront
+template <class E, template <class> class ModelT>
+__global__ void __launch_bounds__(BLOCK) k_adjoint_local_closed(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int first, int count) {
+  constexpr int WPB = BLOCK / 64;
+  __shared__ GradWaveShared<E> shs[WPB];
+  int const wib = C8_WAVE_IN_BLOCK(WPB), lane = threadIdx.x & 63;
+  int const gidx = blockIdx.x * WPB + wib;
+  if (gidx * 8 >= count) return;
+  NoLane L;
+  GpuExec<NoLane> ex(lane, L);
+  adjoint_local_closed_wave8<E, ModelT>(ex, shs[wib], mt, ms, fa, aa, first + gidx * 8, (count - gidx * 8 < 8) ? count - gidx * 8 : 8);
+}
+template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local_closed(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  if (a.count <= 0) return hipSuccess;
+  int const ngroups = (a.count + 7) / 8;
+  hipLaunchKernelGGL((k_adjoint_local_closed<E, ModelT>), dim3((ngroups + WPB - 1) / WPB), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.first, a.count);
+  return hipGetLastError();
+}
 template <class E, template <class> class ModelT> static hipError_t launch_adjoint_local_wave(LaunchArgs const& a) {
   constexpr int WPB = JBLOCK / 64;
   int const nblocks = (a.count + WPB - 1) / WPB;
@@ -494,10 +514,12 @@ static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms
 }
 template <class E, template <class> class ModelT, class = void> struct NodeKernel {
   static NodeRowsFn get() { return nullptr; }
+  static LaunchFn get_adjoint_local() { return nullptr; }
 };
 template <template <class> class ModelT>
 struct NodeKernel<Elem<C8_HEX8>, ModelT, std::enable_if_t<has_closed_form_rows<ModelT<Dual>>::value>> {
   static NodeRowsFn get() { return &launch_node_rows<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_adjoint_local() { return &launch_adjoint_local_closed<Elem<C8_HEX8>, ModelT>; }
 };
 
 // group index -> element for the colour-batched / atomic element-parallel kernels
@@ -685,6 +707,7 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.shape_stride = SHAPE_STRIDE;
   ks.gather_rows = &launch_gather_rows<E>;
   ks.node_rows = NodeKernel<E, ModelT>::get();
+  ks.adjoint_local_closed = NodeKernel<E, ModelT>::get_adjoint_local();
   ks.stage_stride = stage_stride<E>();
   ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements
   ks.can_stage = E::DIM == 3;              // the stage and the row-sum kernel are laid out for 3 + 1 equations per node

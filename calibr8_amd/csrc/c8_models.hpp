@@ -389,6 +389,60 @@ template <class T, int DIM> struct SmallJ2Dim {
     Re[4] = ca * n[5] + omt * G[4];
     Re[5] = ca * (n[8] - trn3) + omt * (G[5] - trG3);
   }
+  // The local adjoint solve (evaluations.cpp:528-659) in closed form: phi = (dC/dxi)^-T v with v = g - (dR/dxi)^T z, and
+  // the history term of the previous step g' = -(dC/dxi_prev)^T phi.  With e = pstrain (packed 00 01 02 11 12 22; w_k = 2 for
+  // the off-diagonal entries, which stand for two tensor entries), s = 2 mu (dev eps - e), n = s / |s|, beta = 2 mu dgam / |s|
+  // = (1 - theta) / theta, kap = sqrt(2/3) K / mu, the plastic branch has
+  //   dC_e / de [de] = (1 + beta) de - beta n (n : de),  dC_e / dalpha = -sqrt(3/2) n,  dC_alpha / de [de] = -2 n : de,
+  //   dC_alpha / dalpha = -kap;      dC_e / de_prev = -I,  dC_e / dalpha_prev = sqrt(3/2) n,  dC_alpha / dxi_prev = 0,
+  // so that with nv = sum_k n_k v_k (packed, unweighted; sum_k w_k n_k^2 = 1)
+  //   phi_alpha = -(v_alpha + sqrt(3/2) nv) / (sqrt 6 + kap),   a = sum_k n_k phi_k = nv + 2 phi_alpha,
+  //   phi_k = (v_k + w_k n_k (beta a + 2 phi_alpha)) / (1 + beta),   g'_k = phi_k,   g'_alpha = -sqrt(3/2) a.
+  // Elastic points: C = xi - xi_prev, phi = v, g' = phi.  (dR/dxi)^T z = -2 mu w dv (E_k : grad z_u): the stress is the only
+  // flux that sees xi.  t: what closed_form left for the tangent (a = 2 mu theta, n); ZG: grad z_u row-major (0..8).
+  C8_HD static void closed_form_local_adjoint(double const* prm, double const* t, double wdv, double const* ZG, double const* g_in,
+                                              double* phi, double* g_out) {
+    static_assert(DIM == 3, "3-D form");
+    double const sqrt_32 = 1.22474487139158904910, sqrt_6 = 2.44948974278317809820, sqrt_23 = 0.81649658092772603273;
+    double const mu = prm[0] * c8_rcp(2. * (1. + prm[1]));
+    double const c = 2. * mu * wdv;
+    double const* nn = t + 5;
+    double const n[6] = {nn[0], nn[1], nn[2], nn[4], nn[5], nn[8]};
+    double v[NLOC];
+    v[0] = g_in[0] + c * ZG[0];
+    v[1] = g_in[1] + c * (ZG[1] + ZG[3]);
+    v[2] = g_in[2] + c * (ZG[2] + ZG[6]);
+    v[3] = g_in[3] + c * ZG[4];
+    v[4] = g_in[4] + c * (ZG[5] + ZG[7]);
+    v[5] = g_in[5] + c * ZG[8];
+    v[NSYM] = g_in[NSYM];
+    bool plastic = false;
+    C8_UNROLL
+    for (int k = 0; k < 9; ++k) plastic = plastic || (nn[k] != 0.);
+    if (!plastic) {
+      C8_UNROLL
+      for (int k = 0; k < NLOC; ++k) { phi[k] = v[k]; g_out[k] = v[k]; }
+      return;
+    }
+    double const theta = t[0] * c8_rcp(2. * mu);
+    double const beta = (1. - theta) * c8_rcp(theta);
+    double const kap = sqrt_23 * prm[2] * c8_rcp(mu);
+    double nv = 0.;
+    C8_UNROLL
+    for (int k = 0; k < 6; ++k) nv += n[k] * v[k];
+    double const pa = -(v[NSYM] + sqrt_32 * nv) * c8_rcp(sqrt_6 + kap);
+    double const a = nv + 2. * pa;
+    double const f = beta * a + 2. * pa;
+    double const ib = c8_rcp(1. + beta);
+    C8_UNROLL
+    for (int k = 0; k < 6; ++k) {
+      double const wk = (k == 1 || k == 2 || k == 4) ? 2. : 1.;
+      phi[k] = (v[k] + wk * n[k] * f) * ib;
+      g_out[k] = phi[k];
+    }
+    phi[NSYM] = pa;
+    g_out[NSYM] = -sqrt_32 * a;
+  }
   // J[4 i + k] += block entry (row i of the row node, column k of the column node; 3 = p)
   C8_HD static void closed_form_block(double const* r, double const* el, double const* h, double Nm, double* J) {
     double const gh = r[0] * h[0] + r[1] * h[1] + r[2] * h[2];

@@ -77,7 +77,7 @@ template <class Lane, int NDOF> struct CpuExec {
   }
 };
 
-enum { K_ADJ_JAC_NODE = 15, K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_ADJ_LOCAL_CLOSED = 16, K_ADJ_JAC_NODE = 15, K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 // objective configuration for the next calls (what c8_set_qoi_calibration / c8_set_measured keep in the context)
 struct EmuQoi {
@@ -216,6 +216,18 @@ template <template <class> class ModelT> static void run_wave_adjoint(Call const
   delete sh;
 }
 
+// K4 in the model's closed form, eight elements per "wavefront" (adjoint_local_closed_wave8)
+template <template <class> class ModelT> static void run_adjoint_local_closed(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  auto* sh = new GradWaveShared<E>();
+  struct NoLane {};
+  auto* ex = new CpuExec<NoLane, 64>();
+  for (int e0 = 0; e0 < c.nelems; e0 += 8)
+    adjoint_local_closed_wave8<E, ModelT>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e0, std::min(8, c.nelems - e0));
+  delete ex;
+  delete sh;
+}
+
 template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
@@ -312,6 +324,13 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
   if (c.what == K_FORWARD_NODE || c.what == K_ADJ_JAC_NODE) {
     if (E::TYPE != C8_HEX8) return -4;
     if (model == "small_J2") return run_node_rows<SmallJ2>(c);
+    return -4;
+  }
+  if (c.what == K_ADJ_LOCAL_CLOSED) {
+    if (E::TYPE != C8_HEX8) return -4;
+    if constexpr (E::TYPE == C8_HEX8) {
+      if (model == "small_J2") { run_adjoint_local_closed<SmallJ2>(c); return 0; }
+    }
     return -4;
   }
   if (c.what == K_QOI_WAVE) {

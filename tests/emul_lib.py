@@ -16,7 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE, K_ADJ_JAC_NODE = 11, 12, 13, 14, 15
+K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE, K_ADJ_JAC_NODE, K_ADJ_LOCAL_CLOSED = 11, 12, 13, 14, 15, 16
 
 
 def lib():
@@ -108,7 +108,8 @@ class Emul:
         return self._call(what, {**self._fields(u, p, up, pp, xip, xi), **self._sys(ls), 12: g, 13: f})
 
     def solve_adjoint_local(self, u, p, up, pp, xip, xi, z_u, z_p, phi, g, f):
-        return self._call(K_ADJ_LOCAL_WAVE if self.wave else K_ADJ_LOCAL, {**self._fields(u, p, up, pp, xip, xi), 12: g, 13: f, 14: z_u, 15: z_p,
+        # node: the library's choice for a model with a closed form on hex8 (K4 in closed form beside the row-per-node assemblies)
+        return self._call(K_ADJ_LOCAL_CLOSED if self.node else K_ADJ_LOCAL_WAVE if self.wave else K_ADJ_LOCAL, {**self._fields(u, p, up, pp, xip, xi), 12: g, 13: f, 14: z_u, 15: z_p,
                                         16: phi})
 
     def qoi_gradient(self, u, p, up, pp, xip, xi, z_u, z_p, phi, nparams):

@@ -265,9 +265,18 @@ def test_adjoint_row_per_node_kernel_against_iterated_form():
         ls = asm.new_linsys()
         assert asm.adjoint_jacobian(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, g, f, ls) == 0
         assert torch.equal(g, g_in)  # average displacement: dJ/dxi = 0
-        res.append(ls.flat.clone())
-    assert torch.equal(res[0], res[2])
-    assert float((res[0] - res[1]).abs().max() / res[1].abs().max()) < 1e-12
+        # K4 on the same states with a non-zero adjoint z: closed form (node / auto) against dual numbers + elimination (wave)
+        zu, zpp = (1e-2 * torch.randn(u1.shape, generator=gen, dtype=torch.float64)).to(asm.device), \
+            (1e-2 * torch.randn(p1.shape, generator=gen, dtype=torch.float64)).to(asm.device)
+        phi = torch.full_like(g, 7.0)
+        f.fill_(7.0)
+        assert asm.solve_adjoint_local(1.5 * u1, 1.5 * p1, u1, p1, xi1, xi2, zu, zpp, phi, g, f) == 0
+        assert float(f.abs().max()) == 0.0  # small strain: no dependence on the previous displacement
+        res.append((ls.flat.clone(), phi.clone(), g.clone()))
+    for k in range(3):
+        assert torch.equal(res[0][k], res[2][k])
+        assert float((res[0][k] - res[1][k]).abs().max() / res[1][k].abs().max()) < 1e-12
+    assert float((res[0][1][:, :, 6] != res[0][2][:, :, 6]).double().mean()) > 0.3  # plastic points: g' differs from phi in the alpha entry
 
 
 def test_row_per_node_kernel_ragged_meshes_sets_and_refusals():
