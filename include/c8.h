@@ -188,7 +188,9 @@ int c8_set_shape_cache(c8_ctx* ctx, int on);
  * reproducible, a third of the staged form's memory traffic.  C8_KERNEL_AUTO takes it where it applies (cached shape
  * tables present, st->xi and st->xi_prev distinct arrays); C8_KERNEL_WAVE keeps the staged one-wavefront-per-element form.
  * It honours c8_set_assign_mode and c8_set_gather_early_nodes / c8_gather_finish like the staged form; between the
- * assembly call and c8_gather_finish the arrays of `st` must stay as they were (the second part reads them). */
+ * assembly call and c8_gather_finish the arrays of `st` must stay as they were (the second part reads them).
+ * Under C8_KERNEL_AUTO / C8_KERNEL_NODE c8_assemble_adjoint_jacobian takes the same form and c8_solve_adjoint_local the
+ * model's closed form of the local adjoint solve (no dual numbers, no elimination of dC/dxi; same results to rounding). */
 int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 /* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
  * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */
