@@ -680,7 +680,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     if (ADJOINT) {  // evaluate at the stored state with xi seeded -> dC/dxi; dJ/dxi; g -= dJ/dxi  (:442-446, :474-481)
       r.converged = true;
       if (Model::HAS_LOCAL) {
-        r.m.evaluate(r.g, ms.abs_tol);
+        r.m.evaluate(r.g, ms.abs_tol, trial_values<ModelT>(r.m, r.g));  // xi seeded: the trial state carries no tangent
         if (d < NL) {
           C8_UNROLL
           for (int j = 0; j < NL; ++j) sh.M[pt][j][d] = r.m.R[j].d;
@@ -1394,7 +1394,7 @@ C8_HD void adjoint_local_wave(EX& ex, WaveSharedA<E, ModelT<Dual>::NLOC>& sh, Me
     MechFlux<Dual> f;
     Mechanics::flux_coupled(r.m, r.g, sh.h, ms.stab_mult, f);
     double const dRz = flux_dot_zq(sh, pt, f);
-    r.m.evaluate(r.g, ms.abs_tol);
+    r.m.evaluate(r.g, ms.abs_tol, trial_values<ModelT>(r.m, r.g));  // xi seeded: the trial state carries no tangent
     if (d < NL) {
       C8_UNROLL
       for (int j = 0; j < NL; ++j) sh.M[pt][d][j] = r.m.R[j].d;  // transposed fill
