@@ -409,29 +409,29 @@ C8_HD bool gj_solve_grouped(EX& ex, GetM getm, GetB getb, Active active) {
 // Model::trial for the local Newton iteration: its arguments (the point quantities, the previous local state, the parameters)
 // carry no tangent there -- the seeds sit in xi --, so it is evaluated in plain doubles (the model's double instantiation, the
 // arithmetic of the dual numbers' value parts) instead of dual numbers whose tangent halves are all zero.
-template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial trial_values(ModelT<Dual> const& m, PointState<Dual> const& g) {
+template <template <class> class ModelT> C8_HD void model_values(ModelT<Dual> const& m, PointState<Dual> const& g, ModelT<double>& md, PointState<double>& gd) {
+  C8_UNROLL
+  for (int k = 0; k < ModelT<Dual>::NPARAMS; ++k) md.params[k] = m.params[k].v;
+  C8_UNROLL
+  for (int k = 0; k < ModelT<Dual>::NLOC; ++k) { md.xi[k] = m.xi[k].v; md.xi_prev[k] = m.xi_prev[k].v; }
+  C8_UNROLL
+  for (int k = 0; k < 3; ++k) { gd.u[k] = g.u[k].v; gd.grad_p[k] = g.grad_p[k].v; }
+  gd.p = g.p.v;
+  auto vals = [](Tens3<Dual> const& a) {
+    Tens3<double> b;
+    b.xx = a.xx.v; b.xy = a.xy.v; b.xz = a.xz.v; b.yx = a.yx.v; b.yy = a.yy.v; b.yz = a.yz.v; b.zx = a.zx.v; b.zy = a.zy.v; b.zz = a.zz.v;
+    return b;
+  };
+  gd.grad_u = vals(g.grad_u);
+  gd.grad_u_prev = vals(g.grad_u_prev);
+}
+template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial trial_of(ModelT<double> const& md, PointState<double> const& gd) {
   using TD = typename ModelT<Dual>::Trial;
   if constexpr (std::is_same<TD, NoTrial>::value) {
     return TD{};
   } else {
     using T1 = typename ModelT<double>::Trial;
     static_assert(sizeof(TD) == sizeof(T1) / sizeof(double) * sizeof(Dual), "Trial: an aggregate of T");
-    ModelT<double> md;
-    C8_UNROLL
-    for (int k = 0; k < ModelT<Dual>::NPARAMS; ++k) md.params[k] = m.params[k].v;
-    C8_UNROLL
-    for (int k = 0; k < ModelT<Dual>::NLOC; ++k) { md.xi[k] = m.xi[k].v; md.xi_prev[k] = m.xi_prev[k].v; }
-    PointState<double> gd;
-    C8_UNROLL
-    for (int k = 0; k < 3; ++k) { gd.u[k] = g.u[k].v; gd.grad_p[k] = g.grad_p[k].v; }
-    gd.p = g.p.v;
-    auto vals = [](Tens3<Dual> const& a) {
-      Tens3<double> b;
-      b.xx = a.xx.v; b.xy = a.xy.v; b.xz = a.xz.v; b.yx = a.yx.v; b.yy = a.yy.v; b.yz = a.yz.v; b.zx = a.zx.v; b.zy = a.zy.v; b.zz = a.zz.v;
-      return b;
-    };
-    gd.grad_u = vals(g.grad_u);
-    gd.grad_u_prev = vals(g.grad_u_prev);
     T1 const t = md.trial(gd);
     TD out;
     double const* const src = reinterpret_cast<double const*>(&t);
@@ -440,6 +440,28 @@ template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial tria
     for (int k = 0; k < (int)(sizeof(T1) / sizeof(double)); ++k) dst[k] = Dual(src[k]);
     return out;
   }
+}
+template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial trial_values(ModelT<Dual> const& m, PointState<Dual> const& g) {
+  if constexpr (std::is_same<typename ModelT<Dual>::Trial, NoTrial>::value) {
+    return {};
+  } else {
+    ModelT<double> md;
+    PointState<double> gd;
+    model_values<ModelT>(m, g, md, gd);
+    return trial_of<ModelT>(md, gd);
+  }
+}
+// The start of the local Newton iteration: the model's initial guess (values only by definition: solve_nonlinear of every
+// model sets the VALUES of xi) and its trial state, both from one pass through the model's double instantiation -- the
+// reference's guesses of the finite-deformation models are their trial states, which the dual-number form evaluated twice.
+template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial guess_and_trial_values(ModelT<Dual>& m, PointState<Dual> const& g) {
+  ModelT<double> md;
+  PointState<double> gd;
+  model_values<ModelT>(m, g, md, gd);
+  md.initial_guess(gd);
+  C8_UNROLL
+  for (int k = 0; k < ModelT<Dual>::NLOC; ++k) m.xi[k].v = md.xi[k];
+  return trial_of<ModelT>(md, gd);
 }
 
 // ---- local Newton iteration with line search in the 8-lanes-per-point layout (the lane-group form with its references:
@@ -450,9 +472,7 @@ template <template <class> class ModelT> C8_HD typename ModelT<Dual>::Trial tria
 template <int NL, bool PIN, template <class> class ModelT, class EX, class SH>
 C8_HD void local_newton_line_search_wave(EX& ex, SH& sh, ModelSettings const& ms) {
   // the kinematic part of the residual (Model::trial) once per point, in plain doubles (trial_values), not in every evaluation
-  constexpr bool CACHED = !std::is_same<typename ModelT<Dual>::Trial, NoTrial>::value;
-  if constexpr (CACHED)
-    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = trial_values<ModelT>(r.m, r.g); });
+  constexpr bool CACHED = !std::is_same<typename ModelT<Dual>::Trial, NoTrial>::value;  // r.trial: set with the initial guess
   auto eval = [&](auto& r, bool force) __attribute__((always_inline)) {
     if constexpr (CACHED) return r.m.evaluate(r.g, ms.abs_tol, r.trial, force, r.path);
     else return r.m.evaluate(r.g, ms.abs_tol, force, r.path);
@@ -673,7 +693,7 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
       r.m.xi[j] = Dual(sh.xi[pt][j], (j == d) ? 1. : 0.);
       r.m.R[j] = Dual(0.);
     }
-    if (!ADJOINT) r.m.initial_guess(r.g);
+    if (!ADJOINT) r.trial = guess_and_trial_values<ModelT>(r.m, r.g);  // the guess, and the trial state of the iteration below
     r.iter = 1;
     r.R_norm_0 = 1.;
     r.converged = !Model::HAS_LOCAL;
@@ -699,7 +719,6 @@ C8_HD void jacobian_wave(EX& ex, SH& sh, MeshTables const& mt, ModelSettings con
     if (!ADJOINT) local_newton_line_search_wave<NL, PIN, ModelT>(ex, sh, ms);
   } else if (Model::HAS_LOCAL && !ADJOINT) {
     auto running = [&](int lane) { auto& r = ex.lane(lane); return (r.iter <= ms.max_iters) && !r.converged; };
-    ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane); auto& r = ex.lane(lane); r.trial = trial_values<ModelT>(r.m, r.g); });  // once per point, not per iteration
     while (ex.any(running)) {
       ex.each([&](int lane_) { int lane = lane_; if constexpr (PIN) C8_PIN(lane);
         auto& r = ex.lane(lane);
