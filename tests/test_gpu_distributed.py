@@ -127,6 +127,7 @@ def halo_worker(rank, world, port, out, n, pdims):
             e_hip = owned_rows_error(asm, plan, ls, ref.rowptr, ref.colidx, hipA, hipb, len(c))
             e_orc = owned_rows_error(asm, plan, ls, orc.rowptr, orc.colidx, ols.A, ols.b, len(c))
             res[tag] = (max(e_hip.values()), max(e_orc.values()))
+            res[tag + "_blocks"] = {k: (e_hip[k], e_orc[k]) for k in e_hip}  # per block, for the message of a failing assertion
 
         xi0 = asm.new_state()
         fwd = lambda ls, xi: asm.forward_jacobian(du, dp, z3, z1, xi0, xi, ls)
@@ -238,7 +239,7 @@ def test_two_parts_hip_assembly_and_halo_match_single_part_and_oracle():
         res = out[r]
         for tag in ("blocking_gather", "blocking_colored", "blocking_atomic", "split", "split_assign", "overlap_atomic",
                     "k3_blocking", "k3_split"):
-            assert res[tag][0] < 1e-12 and res[tag][1] < 1e-12, (r, tag, res[tag])
+            assert res[tag][0] < 1e-12 and res[tag][1] < 1e-12, (r, tag, res[tag], res.get(tag + "_blocks"))
         assert res["xi"] < 1e-14 and res["k3_g"] < 1e-14, (r, res["xi"], res["k3_g"])
         assert res["split_bitwise_equals_blocking"], r
         assert res["c1"] < 1e-12 and res["c1_leaves_A"] and res["c3"] and res["c45"], (r, res)
