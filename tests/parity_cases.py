@@ -300,7 +300,11 @@ def check_two_element_sets(factory, kind, tol, wave=None):
     orc.adjoint_jacobian(u, p, up, pp, xip, xi, g, f, orc.new_linsys())
     z_u, z_p = rng.standard_normal(len(u)) * 1e-3, rng.standard_normal(len(p)) * 1e-3
     phi = np.zeros_like(g)
+    g_d, f_d, phi_d = g.copy(), f.copy(), np.zeros_like(g)
     orc.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g, f)
+    # the local adjoint solve with per-set parameters (the device's own kernel choice: closed form where the model has one)
+    dut.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi_d, g_d, f_d)
+    assert rel_vec(phi_d, phi) < tol and rel_vec(g_d, g) < tol and np.abs(f_d - f).max() <= tol * max(1.0, np.abs(f).max()), (rel_vec(phi_d, phi), rel_vec(g_d, g))
     gr_o, gr_scale = orc.qoi_gradient_with_scale(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
     gr_d = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 5)
     # per component at `tol` against the sum of the magnitudes of the products summed into it (see check_adjoint_chain)
