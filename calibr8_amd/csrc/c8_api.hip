@@ -673,6 +673,9 @@ int c8_param_gradient(c8_ctx* c, const c8_state* st, const double* const z[2], c
   AdjointArgs aa{nullptr, nullptr, z[0], z[1], const_cast<double*>(phi), grad, c->d_active, c8_qoi_args(c)};
   LaunchFn fn = c->ks.param_gradient;
   if (c->ks.param_gradient_wave && c->kernel_variant != C8_KERNEL_SLOT) fn = c->ks.param_gradient_wave;
+  // the model's closed form (hex8 small_J2), where the caller leaves the kernel choice to the library
+  if (c->ks.param_gradient_closed && c->ms.closed_form && !c->subset && (c->kernel_variant == C8_KERNEL_AUTO || c->kernel_variant == C8_KERNEL_NODE))
+    fn = c->ks.param_gradient_closed;
   return run(c, fn, field_args(st), aa, SystemArgs{}, false, "c8_param_gradient");
 }
 

@@ -1723,7 +1723,7 @@ template <class EX> C8_HD void param_gradient_wave8_flush(EX& ex, double* red, A
   });
 }
 
-template <class E, template <class> class ModelT, class QoI, class EX>
+template <class E, template <class> class ModelT, class QoI, bool CLOSED = false, class EX>
 C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const& mt, ModelSettings const& ms,
                                 FieldArgs const& fa, AdjointArgs const& aa, int e0, int count) {
   using Model = ModelT<Dual>;
@@ -1784,9 +1784,24 @@ C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const&
     r.g.p = Dual(gq.p);
     C8_UNROLL
     for (int l = 0; l < 3; ++l) { r.g.grad_p[l] = Dual(gq.grad_p[l]); r.g.u[l] = Dual(gq.u[l]); }
+    double qv[WQ], xiv[NL], phv[NL];  // CLOSED: the model's closed form (Model::closed_form_param_gradient) instead of dual numbers
+    if constexpr (CLOSED) {
+      double const qq[WQ] = {gq.grad_u.xx, gq.grad_u.xy, gq.grad_u.xz, gq.grad_u.yx, gq.grad_u.yy, gq.grad_u.yz, gq.grad_u.zx, gq.grad_u.zy,
+                             gq.grad_u.zz, gq.p, gq.grad_p[0], gq.grad_p[1], gq.grad_p[2], gq.u[0], gq.u[1], gq.u[2]};
+      C8_UNROLL
+      for (int k = 0; k < WQ; ++k) qv[k] = qq[k];
+      C8_UNROLL
+      for (int j = 0; j < NL; ++j) { xiv[j] = fa.xi[qp * NL + j]; phv[j] = aa.phi[qp * NL + j]; }
+    }
     C8_NOUNROLL
     for (int a = 0; a < nact; ++a) {
       int const mine = act[2 + a];
+      double s = 0.;
+      if constexpr (CLOSED) {
+        double const wload = aa.qoi.c_load * wdv;
+        s = Model::closed_form_param_gradient(mt.params + (size_t)es * Model::NPARAMS, qv, xiv, ms.abs_tol, sh.h[el], ms.stab_mult, wdv, ZG,
+                                              phv, mine, wload, aa.qoi.comp, wload != 0. ? aa.qoi.S + qp * 3 : qv);
+      } else {
       C8_UNROLL
       for (int q = 0; q < Model::NPARAMS; ++q)
         r.m.params[q] = Dual(mt.params[es * Model::NPARAMS + q], (q == mine) ? 1. : 0.);
@@ -1797,7 +1812,6 @@ C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const&
         r.m.R[j] = Dual(0.);
       }
       r.m.evaluate(r.g, ms.abs_tol);
-      double s = 0.;
       C8_UNROLL
       for (int j = 0; j < NL; ++j) s += r.m.R[j].d * aa.phi[qp * NL + j];      // (dC/dp)^T phi (:864-866)
       s += QoI::evaluate(r.g, r.m, wdv, aa.qoi, qp).d;                       // dJ/dp (:869-871)
@@ -1809,6 +1823,7 @@ C8_HD void param_gradient_wave8(EX& ex, GradWaveShared<E>& sh, MeshTables const&
       t += f.Gu.yx.d * ZG[3] + f.Gu.yy.d * ZG[4] + f.Gu.yz.d * ZG[5];
       t += f.Gu.zx.d * ZG[6] + f.Gu.zy.d * ZG[7] + f.Gu.zz.d * ZG[8];
       s += t * wdv;                                                          // (dR/dp)^T z (:883-886)
+      }
       // branch-free with static indices: a conditional update makes the compiler index acc dynamically (scratch)
       static_for<8>([&](auto ac) {
         constexpr int k = decltype(ac)::value;

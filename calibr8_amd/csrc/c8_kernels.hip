@@ -317,8 +317,9 @@ k_adjoint_local_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs 
   adjoint_local_wave<E, ModelT>(ex, shs[wib], mt, ms, fa, aa, sa, first + gi);
 }
 
-template <class E, template <class> class ModelT>
-__global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k_param_gradient_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
+// CLOSED: the model's closed form of the point's share (Model::closed_form_param_gradient) instead of dual numbers
+template <class E, template <class> class ModelT, bool CLOSED = false>
+__global__ void __launch_bounds__(BLOCK, CLOSED ? 2 : ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k_param_gradient_wave(MeshTables mt, ModelSettings ms, FieldArgs fa, AdjointArgs aa, int count) {
   constexpr int WPB = BLOCK / 64;
   using Lane = GradWaveLane<ModelT>;
   __shared__ GradWaveShared<E> shs[WPB];
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(BLOCK, ModelT<Dual>::WAVE_BLOCKS_PER_CU_ADJ) k
   GpuExec<Lane> ex(lane, L);
   int const ngroups = (count + 7) / 8;
   for (int gidx = blockIdx.x * WPB + wib; gidx < ngroups; gidx += gridDim.x * WPB)
-    param_gradient_wave8<E, ModelT, PointQoi>(ex, shs[wib], mt, ms, fa, aa, gidx * 8, (count - gidx * 8 < 8) ? count - gidx * 8 : 8);
+    param_gradient_wave8<E, ModelT, PointQoi, CLOSED>(ex, shs[wib], mt, ms, fa, aa, gidx * 8, (count - gidx * 8 < 8) ? count - gidx * 8 : 8);
   param_gradient_wave8_flush(ex, shs[wib].red, aa);
 }
 
@@ -371,6 +372,15 @@ template <class E, template <class> class ModelT> static hipError_t launch_param
   int const nblocks = (ngroups + WPB - 1) / WPB;
   int const grid = nblocks < 2048 ? nblocks : 2048;
   hipLaunchKernelGGL((k_param_gradient_wave<E, ModelT>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.count);
+  return hipGetLastError();
+}
+template <class E, template <class> class ModelT> static hipError_t launch_param_gradient_closed(LaunchArgs const& a) {
+  constexpr int WPB = BLOCK / 64;
+  if (a.count <= 0) return hipSuccess;
+  int const ngroups = (a.count + 7) / 8;
+  int const nblocks = (ngroups + WPB - 1) / WPB;
+  int const grid = nblocks < 2048 ? nblocks : 2048;
+  hipLaunchKernelGGL((k_param_gradient_wave<E, ModelT, true>), dim3(grid), dim3(BLOCK), 0, a.stream, a.mt, a.ms, a.fa, a.aa, a.count);
   return hipGetLastError();
 }
 
@@ -515,11 +525,13 @@ static hipError_t launch_node_rows(MeshTables const& mt, ModelSettings const& ms
 template <class E, template <class> class ModelT, class = void> struct NodeKernel {
   static NodeRowsFn get() { return nullptr; }
   static LaunchFn get_adjoint_local() { return nullptr; }
+  static LaunchFn get_param_gradient() { return nullptr; }
 };
 template <template <class> class ModelT>
 struct NodeKernel<Elem<C8_HEX8>, ModelT, std::enable_if_t<has_closed_form_rows<ModelT<Dual>>::value>> {
   static NodeRowsFn get() { return &launch_node_rows<Elem<C8_HEX8>, ModelT>; }
   static LaunchFn get_adjoint_local() { return &launch_adjoint_local_closed<Elem<C8_HEX8>, ModelT>; }
+  static LaunchFn get_param_gradient() { return &launch_param_gradient_closed<Elem<C8_HEX8>, ModelT>; }
 };
 
 // group index -> element for the colour-batched / atomic element-parallel kernels
@@ -708,6 +720,7 @@ template <class E, template <class> class ModelT> static KernelSet kernel_set() 
   ks.gather_rows = &launch_gather_rows<E>;
   ks.node_rows = NodeKernel<E, ModelT>::get();
   ks.adjoint_local_closed = NodeKernel<E, ModelT>::get_adjoint_local();
+  ks.param_gradient_closed = NodeKernel<E, ModelT>::get_param_gradient();
   ks.stage_stride = stage_stride<E>();
   ks.adjoint_slot_stages = E::NDOF <= 16;  // the slot-per-lane adjoint kernel holds assembled columns only for small elements
   ks.can_stage = E::DIM == 3;              // the stage and the row-sum kernel are laid out for 3 + 1 equations per node

@@ -40,6 +40,7 @@ struct KernelSet {
   LaunchFn param_gradient;     // K5 (grid-stride, one atomic per lane at the end)
   LaunchFn adjoint_local_wave;     // K4, one wavefront per element (hex8 only, else null)
   LaunchFn adjoint_local_closed;   // K4 in the model's closed form, eight elements per wavefront (hex8 models with one, else null)
+  LaunchFn param_gradient_closed;  // K5 likewise
   LaunchFn param_gradient_wave;    // K5, one wavefront per element (hex8 only, else null)
   LaunchFn qoi;                // K6 (hex8: eight elements per wavefront)
   LaunchFn qoi_slot;           // K6, one lane per point of a lane group (any element type)

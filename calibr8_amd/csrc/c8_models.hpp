@@ -443,6 +443,52 @@ template <class T, int DIM> struct SmallJ2Dim {
     phi[NSYM] = pa;
     g_out[NSYM] = -sqrt_32 * a;
   }
+  // The point's share of the parameter gradient (eval_qoi_gradient, evaluations.cpp:758-925) for parameter `mine` (E nu K Y cte
+  // delta_T) at the stored state, in closed form: (dC/dp)^T phi + dJ/dp + (dR/dp)^T z.  The local residual sees the parameters
+  // through C_alpha = (|s| - sqrt(2/3)(Y + K alpha)) / val(mu) only (plastic points; n = s / |s| does not depend on mu), the
+  // fluxes through mu (stress 2 mu D, D = dev eps - pstrain; stabilisation tau = stab h^2 / (2 mu)), kappa (-p / kappa) and
+  // the thermal term cte delta_T E / ((1 - 2 nu) kappa), whose E and nu derivatives cancel; the load term of the
+  // calibration objective through the stress.  q: grad u (0..8), p (9), grad p (10..12); ZG likewise for the adjoint z.
+  C8_HD static double closed_form_param_gradient(double const* prm, double const* q, double const* xi, double abs_tol, double h,
+                                                 double stab_mult, double wdv, double const* ZG, double const* phi, int mine,
+                                                 double wload, int comp, double const* S) {
+    static_assert(DIM == 3, "3-D form");
+    double const sqrt_23 = 0.81649658092772603273;
+    double const E = prm[0], nu = prm[1], K = prm[2], Y = prm[3], cte = prm[4], dT = prm[5];
+    double const mu = E * c8_rcp(2. * (1. + nu)), kappa = E * c8_rcp(3. * (1. - 2. * nu));
+    double const dmu = mine == 0 ? mu * c8_rcp(E) : (mine == 1 ? -mu * c8_rcp(1. + nu) : 0.);
+    double const dkap = mine == 0 ? kappa * c8_rcp(E) : (mine == 1 ? 2. * kappa * c8_rcp(1. - 2. * nu) : 0.);
+    double const dK = mine == 2 ? 1. : 0., dY = mine == 3 ? 1. : 0., dcte = mine == 4 ? 1. : 0., ddT = mine == 5 ? 1. : 0.;
+    double eps[9];
+    C8_UNROLL
+    for (int i = 0; i < 3; ++i)
+      C8_UNROLL
+      for (int j = 0; j < 3; ++j) eps[3 * i + j] = 0.5 * (q[3 * i + j] + q[3 * j + i]);
+    double const th = (eps[0] + eps[4] + eps[8]) * (1. / 3.);
+    double const ep[9] = {xi[0], xi[1], xi[2], xi[1], xi[3], xi[4], xi[2], xi[4], xi[5]};
+    double D[9], dd = 0.;
+    C8_UNROLL
+    for (int k = 0; k < 9; ++k) {
+      D[k] = eps[k] - ((k == 0 || k == 4 || k == 8) ? th : 0.) - ep[k];
+      dd += D[k] * D[k];
+    }
+    double const smag = 2. * mu * sqrt(dd);
+    double const alpha = xi[NSYM];
+    double const f = (smag - sqrt_23 * (Y + K * alpha)) * c8_rcp(mu);
+    bool const plastic = f > abs_tol || fabs(f) < abs_tol;
+    double s = 0.;
+    if (plastic) s = phi[NSYM] * (dmu * smag * c8_rcp(mu) - sqrt_23 * (dY + dK * alpha)) * c8_rcp(mu);
+    double DZ = 0.;
+    C8_UNROLL
+    for (int k = 0; k < 9; ++k) DZ += D[k] * ZG[k];
+    double const th3 = E * c8_rcp((1. - 2. * nu) * kappa);  // = 3
+    double const dVp = dkap * q[9] * c8_rcp(kappa * kappa) + (dcte * dT + ddT * cte) * th3;
+    double const tau = (stab_mult * 0.5 * h * h) * c8_rcp(mu);
+    double const dGp = dmu * tau * c8_rcp(mu);
+    s += wdv * (2. * dmu * DZ + dVp * ZG[9] + dGp * (q[10] * ZG[10] + q[11] * ZG[11] + q[12] * ZG[12]));
+    if (wload != 0.) s += 2. * dmu * wload * (D[3 * comp] * S[0] + D[3 * comp + 1] * S[1] + D[3 * comp + 2] * S[2]);
+    return s;
+  }
   // J[4 i + k] += block entry (row i of the row node, column k of the column node; 3 = p)
   C8_HD static void closed_form_block(double const* r, double const* el, double const* h, double Nm, double* J) {
     double const gh = r[0] * h[0] + r[1] * h[1] + r[2] * h[2];

@@ -190,7 +190,8 @@ int c8_set_shape_cache(c8_ctx* ctx, int on);
  * It honours c8_set_assign_mode and c8_set_gather_early_nodes / c8_gather_finish like the staged form; between the
  * assembly call and c8_gather_finish the arrays of `st` must stay as they were (the second part reads them).
  * Under C8_KERNEL_AUTO / C8_KERNEL_NODE c8_assemble_adjoint_jacobian takes the same form and c8_solve_adjoint_local the
- * model's closed form of the local adjoint solve (no dual numbers, no elimination of dC/dxi; same results to rounding). */
+ * model's closed form of the local adjoint solve (no dual numbers, no elimination of dC/dxi; same results to rounding);
+ * c8_param_gradient likewise takes the closed form of the point's share of the gradient. */
 int c8_set_kernel_variant(c8_ctx* ctx, int variant);
 /* async = 1: assembly calls only enqueue and return C8_OK; c8_status() then synchronises the
  * stream and reports C8_OK / C8_LOCAL_SOLVE_FAILED for everything enqueued since the last call. */

@@ -77,7 +77,7 @@ template <class Lane, int NDOF> struct CpuExec {
   }
 };
 
-enum { K_ADJ_LOCAL_CLOSED = 16, K_ADJ_JAC_NODE = 15, K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
+enum { K_GRAD_CLOSED = 17, K_ADJ_LOCAL_CLOSED = 16, K_ADJ_JAC_NODE = 15, K_FORWARD_NODE = 14, K_QOI_PREPROCESS = 13, K_QOI_WAVE = 12, K_RESIDUAL_WAVE = 11, K_ADJ_LOCAL_WAVE = 9, K_GRAD_WAVE = 10, K_ADJ_JAC_WAVE = 8, K_FORWARD_WAVE = 7, K_FORWARD = 1, K_RESIDUAL = 2, K_ADJ_JAC = 3, K_ADJ_LOCAL = 4, K_GRAD = 5, K_QOI = 6 };
 
 // objective configuration for the next calls (what c8_set_qoi_calibration / c8_set_measured keep in the context)
 struct EmuQoi {
@@ -228,6 +228,19 @@ template <template <class> class ModelT> static void run_adjoint_local_closed(Ca
   delete sh;
 }
 
+// K5 in the model's closed form (param_gradient_wave8<CLOSED>)
+template <template <class> class ModelT> static void run_param_gradient_closed(Call const& c) {
+  using E = Elem<C8_HEX8>;
+  auto* sh = new GradWaveShared<E>();
+  auto* ex = new CpuExec<GradWaveLane<ModelT>, 64>();
+  for (int k = 0; k < 64; ++k) { ex->lanes[k].slot0 = -1; for (int a = 0; a < 8; ++a) ex->lanes[k].acc[a] = 0.; }
+  for (int e0 = 0; e0 < c.nelems; e0 += 8)
+    param_gradient_wave8<E, ModelT, PointQoi, true>(*ex, *sh, c.mt, c.ms, c.fa, c.aa, e0, std::min(8, c.nelems - e0));
+  param_gradient_wave8_flush(*ex, sh->red, c.aa);
+  delete ex;
+  delete sh;
+}
+
 template <template <class> class ModelT> static void run_wave(Call const& c) {
   using E = Elem<C8_HEX8>;
   auto* sh = new WaveShared<E, ModelT<Dual>::NLOC>();
@@ -326,10 +339,14 @@ template <class E> static int dispatch(std::string const& model, Call const& c) 
     if (model == "small_J2") return run_node_rows<SmallJ2>(c);
     return -4;
   }
-  if (c.what == K_ADJ_LOCAL_CLOSED) {
+  if (c.what == K_ADJ_LOCAL_CLOSED || c.what == K_GRAD_CLOSED) {
     if (E::TYPE != C8_HEX8) return -4;
     if constexpr (E::TYPE == C8_HEX8) {
-      if (model == "small_J2") { run_adjoint_local_closed<SmallJ2>(c); return 0; }
+      if (model == "small_J2") {
+        if (c.what == K_GRAD_CLOSED) run_param_gradient_closed<SmallJ2>(c);
+        else run_adjoint_local_closed<SmallJ2>(c);
+        return 0;
+      }
     }
     return -4;
   }
@@ -460,7 +477,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
   };
   int const base = c.what;
   bool const is_qoi = base == K_QOI || base == K_QOI_WAVE, is_k3 = base == K_ADJ_JAC || base == K_ADJ_JAC_WAVE || base == K_ADJ_JAC_NODE,
-             is_k5 = base == K_GRAD || base == K_GRAD_WAVE, is_pre = base == K_QOI_PREPROCESS;
+             is_k5 = base == K_GRAD || base == K_GRAD_WAVE || base == K_GRAD_CLOSED, is_pre = base == K_QOI_PREPROCESS;
   if (g_qoi.kind == 1 && (is_qoi || is_k3 || is_k5 || is_pre)) {
     // the sequence of c8_qoi.hip: tables (set-up), preprocess_qoi, then the entry point with the point integrand
     CalibrationTables t;
@@ -471,7 +488,7 @@ extern "C" int c8emu_call(int what, int elem_type, int nnodes, int nelems, doubl
     double total = 0.;
     {
       Call pc = c;
-      pc.what = (elem_type == C8_HEX8 && (base == K_QOI_WAVE || base == K_ADJ_JAC_WAVE || base == K_GRAD_WAVE)) ? K_QOI_WAVE : K_QOI;
+      pc.what = (elem_type == C8_HEX8 && (base == K_QOI_WAVE || base == K_ADJ_JAC_WAVE || base == K_GRAD_WAVE || base == K_GRAD_CLOSED)) ? K_QOI_WAVE : K_QOI;
       pc.staged = 0;
       pc.aa.out = &total;
       pc.aa.qoi = QoiArgs{0., 1., g_qoi.comp, t.S.data(), (double)nd};

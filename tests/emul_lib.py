@@ -16,7 +16,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 _lib = None
 K_FORWARD, K_RESIDUAL, K_ADJ_JAC, K_ADJ_LOCAL, K_GRAD, K_QOI, K_FORWARD_WAVE, K_ADJ_JAC_WAVE, K_ADJ_LOCAL_WAVE, K_GRAD_WAVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE, K_ADJ_JAC_NODE, K_ADJ_LOCAL_CLOSED = 11, 12, 13, 14, 15, 16
+K_RESIDUAL_WAVE, K_QOI_WAVE, K_QOI_PREPROCESS, K_FORWARD_NODE, K_ADJ_JAC_NODE, K_ADJ_LOCAL_CLOSED, K_GRAD_CLOSED = 11, 12, 13, 14, 15, 16, 17
 
 
 def lib():
@@ -114,7 +114,7 @@ class Emul:
 
     def qoi_gradient(self, u, p, up, pp, xip, xi, z_u, z_p, phi, nparams):
         grad = np.zeros(nparams)
-        self._call(K_GRAD_WAVE if self.wave else K_GRAD, {**self._fields(u, p, up, pp, xip, xi), 14: z_u, 15: z_p, 16: phi, 17: grad})
+        self._call(K_GRAD_CLOSED if self.node else K_GRAD_WAVE if self.wave else K_GRAD, {**self._fields(u, p, up, pp, xip, xi), 14: z_u, 15: z_p, 16: phi, 17: grad})
         return grad
 
     # ---- Calibration objective (the emulator keeps one objective configuration, like a context) ----
