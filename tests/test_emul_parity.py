@@ -125,10 +125,18 @@ def test_adjoint_row_per_node_kernel_against_iterated_form():
         dut.wave, dut.node = True, node
         ls, g = dut.new_linsys(), g0.copy()
         assert dut.adjoint_jacobian(u, p, up, pp, xip, xi, g, f0, ls) == 0
-        out.append([g] + ls.b + [ls.A[i][j] for i in range(2) for j in range(2)])
+        # K4 and K5 on the same states with a non-zero adjoint: closed forms (node) against dual numbers + elimination (wave)
+        z_u, z_p = 1e-2 * np.cos(np.arange(len(u))), 1e-2 * np.sin(np.arange(len(p)))
+        phi, g4, f4 = np.full_like(g0, 7.0), g.copy(), np.full_like(f0, 7.0)
+        dut.solve_adjoint_local(u, p, up, pp, xip, xi, z_u, z_p, phi, g4, f4)
+        assert np.abs(f4).max() == 0.0  # small strain: no dependence on the previous displacement
+        dut.set_active(0, [0, 1, 2, 3])
+        grad = dut.qoi_gradient(u, p, up, pp, xip, xi, z_u, z_p, phi, 4)
+        out.append([g] + ls.b + [ls.A[i][j] for i in range(2) for j in range(2)] + [phi, g4, grad])
     for a, b in zip(*out):
         assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
     assert np.array_equal(out[0][0], g0)  # the average-displacement objective leaves g as it is
+    assert (out[0][-3][:, :, 6] != out[0][-2][:, :, 6]).mean() > 0.3  # plastic points: g' differs from phi in the alpha entry
 
 
 def test_row_per_node_kernel_assign_mode_and_ragged_meshes():
